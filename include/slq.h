@@ -1,0 +1,200 @@
+/* slq.h — C-ABI of the MI355X stochastic-Lanczos-quadrature engine (libslq).
+ *
+ * This is the drop-in boundary for the reference's native hot path. Plain pointers, sizes and
+ * opaque handles only; no C++ or torch types cross it. All entry points return 0 on success or a
+ * negative SLQ_E* code (never throw); slq_last_error() gives the message for the calling thread.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo root):
+ *   - primate._lanczos.lanczos(A, v, deg, rtol, orth, alpha, beta, Q)
+ *       src/primate/_lanczos.cpp:88-99 (six overloads registered at :102-112)
+ *       -> slq_lanczos_f64 / slq_lanczos_f32
+ *   - the native kernels behind it, src/primate/include/lanczos.h:43-66 (orth_vector) and
+ *       :92-149 (lanczos_recurrence)              -> the plan's device loop (slq_plan_run)
+ *   - the operator plugin concept, src/primate/include/linear_operator.h:25-29
+ *       (matvec(const F*, F*) + shape())          -> slq_operator (CSR device fast path,
+ *       dense, host-callback fallback; src/primate/include/eigen_operators.h:17-104,
+ *       src/primate/include/pylinop.h:16-73)
+ *   - the per-probe Python loop of MatrixFunction.quad, src/primate/operators.py:138-151,
+ *       with integrate.quadrature (src/primate/integrate.py:57-76) and the LAPACK call in
+ *       src/primate/tridiag.py:10-11               -> slq_quad_batch_* (one call for P probes)
+ *   - random.isotropic, src/primate/random.py:22-41,47-80 -> slq_plan_generate_probes
+ *   - the spectral-function registry, src/primate/special.py:78-107 -> SLQ_FUN_* ids
+ *
+ * Conventions kept from the reference: alpha/beta have deg+1 entries, beta[0] = 0
+ * (lanczos.h:121); rtol is scaled by sqrt(n) (lanczos.h:110); `orth` = number of most recent
+ * Lanczos vectors (current one included) to re-orthogonalise against (lanczos.h:135);
+ * out-of-range orth (<0 or >deg) means deg (src/primate/operators.py:80); probes are column-major
+ * n x P (src/primate/random.py:76); nodes ascending with weights = squared first eigenvector
+ * components (integrate.py:63-64).
+ */
+#ifndef SLQ_H
+#define SLQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLQ_VERSION 100
+
+/* ---- status codes --------------------------------------------------------------------------- */
+enum {
+  SLQ_OK = 0,
+  SLQ_EINVAL = -1,   /* invalid argument (maps to Python AssertionError / ValueError)           */
+  SLQ_ENOMEM = -2,   /* host or device allocation failed                                         */
+  SLQ_EHIP = -3,     /* a HIP runtime call or kernel failed                                      */
+  SLQ_ENODEV = -4,   /* no usable gfx950 device                                                  */
+  SLQ_ECALLBACK = -5, /* a host-callback operator returned non-zero                              */
+  SLQ_ENOTCONV = -6   /* tridiagonal QL did not converge for at least one probe                   */
+};
+
+enum { SLQ_F32 = 0, SLQ_F64 = 1 };
+
+/* Spectral functions; ids and parameter meaning follow src/primate/special.py:78-107:
+ *   EXP {t}: exp(t x) | SMOOTHSTEP {a,b}: y=clip((x-a)/d,0,1), d=b-a (1 if a==b), 3y^2-2y^3 |
+ *   STEP {c, nonnegative}: (|x| or x) < c ? 0 : 1  (numrank = {1e-6, 1}) |
+ *   SOFTSIGN {q} | LOG: log(max(x, eps_f64)) | NONE: skip the reduction (nodes/weights only). */
+enum {
+  SLQ_FUN_IDENTITY = 0,
+  SLQ_FUN_ABS = 1,
+  SLQ_FUN_SQRT = 2,
+  SLQ_FUN_LOG = 3,
+  SLQ_FUN_INV = 4,
+  SLQ_FUN_EXP = 5,
+  SLQ_FUN_SMOOTHSTEP = 6,
+  SLQ_FUN_STEP = 7,
+  SLQ_FUN_SOFTSIGN = 8,
+  SLQ_FUN_NONE = -1
+};
+
+/* Probe distributions (src/primate/random.py:12-18). */
+enum { SLQ_PDF_RADEMACHER = 0, SLQ_PDF_NORMAL = 1, SLQ_PDF_SPHERE = 2 };
+
+typedef struct slq_context slq_context;   /* one per (process, GPU): device id + HIP stream      */
+typedef struct slq_operator slq_operator; /* a symmetric linear operator resident on that GPU    */
+typedef struct slq_plan slq_plan;         /* workspace + state of one batched Lanczos run        */
+
+/* Host-callback operator: y = A x on HOST memory (the fallback for arbitrary Python
+ * LinearOperators; mirrors PyLinearOperator::matvec, src/primate/include/pylinop.h:32-40).
+ * x has ncols entries, y nrows entries, both of the operator's dtype. Return 0 on success. */
+typedef int (*slq_matvec_fn)(void *user, const void *x, void *y);
+
+/* ---- context -------------------------------------------------------------------------------- */
+const char *slq_last_error(void);
+int slq_version(void);
+int slq_device_count(int *count);
+/* device < 0: use the current HIP device. stream == NULL: the context creates its own stream. */
+int slq_context_create(int device, void *hip_stream, slq_context **out);
+int slq_context_destroy(slq_context *ctx);
+int slq_context_synchronize(slq_context *ctx);
+/* bytes free / total on the context's device */
+int slq_context_meminfo(slq_context *ctx, size_t *free_bytes, size_t *total_bytes);
+
+/* ---- operators ------------------------------------------------------------------------------ */
+/* CSR, int32 indices, host arrays: copied to the device once (the reference copies the matrix
+ * at least three times PER PROBE at its FFI, src/primate/_lanczos.cpp:88-93 +
+ * src/primate/include/eigen_operators.h:64). */
+int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr,
+                   const int32_t *colind, const void *vals, slq_operator **out);
+/* Same, arrays already on the device; borrowed for the operator's lifetime (no copy). */
+int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
+                          const int32_t *d_rowptr, const int32_t *d_colind, const void *d_vals,
+                          slq_operator **out);
+/* Dense symmetric n x n, column-major with leading dimension lda (host array, copied). */
+int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const void *A, int64_t lda,
+                     slq_operator **out);
+/* Host-callback operator (device <-> host round trip per Lanczos step and probe). */
+int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_matvec_fn fn, void *user,
+                        slq_operator **out);
+int slq_operator_destroy(slq_operator *op);
+int slq_operator_shape(const slq_operator *op, int64_t *nrows, int64_t *ncols, int64_t *nnz,
+                       int *dtype);
+/* Y = A X for a column-major host panel (n x b, ld); exercises the device SpMM on its own. */
+int slq_operator_matmat(slq_operator *op, const void *X, int64_t ldx, void *Y, int64_t ldy,
+                        int b);
+
+/* ---- plan: batched lock-step Lanczos over P probes --------------------------------------------- */
+/* keep_basis != 0 retains all deg Lanczos vectors (ncv = deg, as MatrixFunction fixes it for the
+ * f(A)v action, src/primate/operators.py:75-77); otherwise only max(orth,2)(+1) ring slots are
+ * resident (ncv = clip(orth, 2, deg), src/primate/lanczos.py:89). */
+int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, int deg, int orth,
+                    int keep_basis, slq_plan **out);
+int slq_plan_destroy(slq_plan *plan);
+/* Device bytes this plan holds / would hold. */
+int slq_plan_workspace_bytes(const slq_plan *plan, size_t *bytes);
+int slq_plan_query_bytes(int dtype, int64_t n, int nprobes, int deg, int orth, int keep_basis,
+                         size_t *bytes);
+
+/* Parity mode: host probes, column-major n x nprobes of the plan's dtype (ld >= n). */
+int slq_plan_set_probes(slq_plan *plan, const void *X, int64_t ldx);
+/* Throughput mode: counter-based Philox4x32-10 on the device; the stream of probe `i` depends
+ * only on (seed, probe_offset + i), so results do not depend on how probes are sharded. */
+int slq_plan_generate_probes(slq_plan *plan, int pdf, uint64_t seed, uint64_t probe_offset);
+/* Copy the current probes back as a column-major n x nprobes host panel. */
+int slq_plan_get_probes(slq_plan *plan, void *X, int64_t ldx);
+
+/* deg Lanczos steps for all probes (asynchronous on the context stream). */
+int slq_plan_run(slq_plan *plan, double rtol);
+/* alpha, beta: nprobes x (deg+1) row-major of the plan dtype; steps: nprobes ints. Any may be
+ * NULL. Synchronises. */
+int slq_plan_get_tridiag(slq_plan *plan, void *alpha, void *beta, int32_t *steps);
+/* Gauss quadrature of every probe's Jacobi matrix on the device, then
+ * quad[i] = sum_k f(nodes[i,k]) * weights[i,k] * ||v_i||^2 (src/primate/operators.py:149-150).
+ * quad: nprobes doubles or NULL; nodes/weights: nprobes x deg row-major doubles or NULL.
+ * Synchronises. */
+int slq_plan_quadrature(slq_plan *plan, int fun_id, const double *fun_params, double *quad,
+                        double *nodes, double *weights);
+/* Lanczos basis of probe `probe` as a column-major n x deg host array (normalised columns;
+ * columns past an early stop are zero). Requires keep_basis. */
+int slq_plan_get_basis(slq_plan *plan, int probe, void *Q, int64_t ldq);
+/* Y[:, i] = f(A) x_i ~= ||x_i|| Q_i Y_i (f(theta_i) * Y_i[0,:])  (src/primate/operators.py:113-124);
+ * column-major n x nprobes host output. Requires keep_basis and a completed run. */
+int slq_plan_fun_action(slq_plan *plan, int fun_id, const double *fun_params, void *Y,
+                        int64_t ldy);
+
+/* Per-kernel device time accumulated by HIP events on the context stream (for bench.py's
+ * roofline line). enable != 0 turns event recording on for subsequent slq_plan_run calls. */
+enum {
+  SLQ_K_SPMM = 0,    /* sweep A: panel SpMM + three-term update + alpha partials                  */
+  SLQ_K_AXPY_NORM,   /* sweep B (orth = 0): w -= alpha q_c, ||w||^2 partials                       */
+  SLQ_K_REORTH_DOT,  /* sweep B (orth > 0): w -= alpha q_c, c = Q_r^T w partials                   */
+  SLQ_K_REORTH_UPD,  /* sweep C: w -= Q_r c, ||w||^2 partials                                      */
+  SLQ_K_FINALIZE,    /* all per-step scalar kernels (partials -> alpha/beta/coefficients)           */
+  SLQ_K_PROBES,      /* probe generation / layout                                                   */
+  SLQ_K_QUADRATURE,  /* tridiagonal eigensolve + f reduction                                        */
+  SLQ_K_COUNT
+};
+typedef struct {
+  double ms[SLQ_K_COUNT];       /* summed device time per class                                   */
+  int64_t launches[SLQ_K_COUNT];
+} slq_profile;
+int slq_plan_profile_enable(slq_plan *plan, int enable);
+int slq_plan_profile_read(slq_plan *plan, slq_profile *out, int reset);
+
+/* ---- one-shot entries ---------------------------------------------------------------------------- */
+/* P probes in one call: the batched counterpart of the Python loop at
+ * src/primate/operators.py:145-150. X: host column-major n x nprobes, or NULL to draw probes on
+ * the device (pdf, seed, probe_offset). quad_out: nprobes doubles. nodes_out / weights_out:
+ * nprobes x deg row-major doubles or NULL. */
+int slq_quad_batch(slq_context *ctx, slq_operator *op, const void *X, int64_t ldx, int pdf,
+                   uint64_t seed, uint64_t probe_offset, int nprobes, int deg, double rtol,
+                   int orth, int fun_id, const double *fun_params, double *quad_out,
+                   double *nodes_out, double *weights_out);
+
+/* Single-vector drop-in for primate._lanczos.lanczos (src/primate/_lanczos.cpp:88-99), host
+ * pointers, same in/out contract: v (n) is scratch and is clobbered; alpha, beta (deg+1) and
+ * Q (n x ncv column-major) are written in place; beta[0] = 0. Q's incoming contents take part in
+ * the re-orthogonalisation exactly as in the reference (columns other than ncv-1 and 0 are not
+ * cleared, src/primate/include/lanczos.h:118-121). Returns the number of executed steps (>= 1)
+ * or a negative error code. */
+int slq_lanczos_f64(slq_context *ctx, slq_operator *op, double *v, int deg, double rtol, int orth,
+                    double *alpha, double *beta, double *Q, size_t ncv);
+int slq_lanczos_f32(slq_context *ctx, slq_operator *op, float *v, int deg, float rtol, int orth,
+                    float *alpha, float *beta, float *Q, size_t ncv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLQ_H */

@@ -1,0 +1,985 @@
+// slq.hip — C-ABI implementation (include/slq.h) over the kernels in slq_kernels.hpp.
+// Host logic only: handles, workspace, launch sequencing, HIP-event profiling.
+// Built with: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see __graft_entry__.build()).
+#include "../../include/slq.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "slq_kernels.hpp"
+
+using namespace slq;
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(_e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "%s failed: %s (%s:%d)",  \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+#define SLQ_TRY(expr)           \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != SLQ_OK) return _rc; \
+  } while (0)
+
+extern "C" const char *slq_last_error(void) { return g_err; }
+extern "C" int slq_version(void) { return SLQ_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------
+struct slq_context {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  int num_cus;
+};
+
+enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2 };
+
+struct slq_operator {
+  slq_context *ctx;
+  int kind, dtype;
+  int64_t n, nnz;
+  int32_t *rowptr, *colind;
+  void *vals;   // CSR values or dense matrix (device)
+  int64_t lda;
+  bool owns;
+  slq_matvec_fn fn;
+  void *user;
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int kind;
+};
+
+struct slq_plan {
+  slq_context *ctx;
+  slq_operator *op;
+  int dtype, n, nprobes, deg, orth, keep_basis;
+  int LPR, PW, NP, bpad, S;
+  size_t esz;
+  int64_t slot_stride;  // elements between ring slots
+  void *ring;
+  void *T;              // product panel for dense / callback operators
+  void *stage;          // column-major staging (probe upload, callback round trips)
+  int stage_cols;
+  StepState st;
+  double *scal;         // one allocation behind all StepState arrays
+  double *part;
+  int nblkA, nblkS;
+  double *quad_d, *nodes_d, *weights_d;
+  int *fail_d;
+  int rmax;
+  bool probes_ready, ran;
+  int pdf_sphere;
+  bool prof;
+  std::vector<ProfEvent> events;
+  std::vector<ProfEvent> pool;
+  slq_profile acc;
+  std::vector<char> hbuf;  // host staging for callback operators
+  size_t bytes;
+};
+
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+extern "C" int slq_device_count(int *count) {
+  if (!count) return fail(SLQ_EINVAL, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SLQ_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = c;
+  return SLQ_OK;
+}
+
+extern "C" int slq_context_create(int device, void *hip_stream, slq_context **out) {
+  if (!out) return fail(SLQ_EINVAL, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(SLQ_ENODEV, "no HIP device visible: the SLQ engine has no CPU fallback");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= count) return fail(SLQ_EINVAL, "device %d out of range (%d visible)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SLQ_ENODEV, "device %d is %s; libslq is built for gfx950 only", device,
+                prop.gcnArchName);
+  slq_context *ctx = new (std::nothrow) slq_context();
+  if (!ctx) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(SLQ_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return SLQ_OK;
+}
+
+extern "C" int slq_context_destroy(slq_context *ctx) {
+  if (!ctx) return SLQ_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SLQ_OK;
+}
+
+extern "C" int slq_context_synchronize(slq_context *ctx) {
+  if (!ctx) return fail(SLQ_EINVAL, "ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SLQ_OK;
+}
+
+extern "C" int slq_context_meminfo(slq_context *ctx, size_t *free_bytes, size_t *total_bytes) {
+  if (!ctx) return fail(SLQ_EINVAL, "ctx is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return SLQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// operators
+// ---------------------------------------------------------------------------------------------------
+static size_t esize(int dtype) { return dtype == SLQ_F64 ? 8 : 4; }
+
+static int check_dtype(int dtype) {
+  if (dtype != SLQ_F32 && dtype != SLQ_F64)
+    return fail(SLQ_EINVAL, "Only 32- or 64-bit floats are supported.");
+  return SLQ_OK;
+}
+
+extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
+                              const int32_t *rowptr, const int32_t *colind, const void *vals,
+                              slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31)
+    return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices (n=%lld, nnz=%lld)",
+                (long long)n, (long long)nnz);
+  if (!rowptr || (nnz > 0 && (!colind || !vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  if (rowptr[0] != 0 || rowptr[n] != nnz)
+    return fail(SLQ_EINVAL, "rowptr[0] must be 0 and rowptr[n] must equal nnz");
+  for (int64_t i = 0; i < n; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(SLQ_EINVAL, "rowptr is not non-decreasing at %lld", (long long)i);
+  for (int64_t p = 0; p < nnz; ++p)
+    if (colind[p] < 0 || colind[p] >= n)
+      return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[p], (long long)p);
+  HIP_TRY(hipSetDevice(ctx->device));
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr};
+  const size_t es = esize(dtype);
+  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, std::max<size_t>((size_t)nnz * 4, 4));
+  if (e == hipSuccess) e = hipMalloc(&op->vals, std::max<size_t>((size_t)nnz * es, 8));
+  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, rowptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, colind, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, vals, (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
+  }
+  *out = op;
+  return SLQ_OK;
+}
+
+extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
+                                     const int32_t *d_rowptr, const int32_t *d_colind,
+                                     const void *d_vals, slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31)
+    return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices");
+  if (!d_rowptr || (nnz > 0 && (!d_colind || !d_vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, const_cast<int32_t *>(d_rowptr),
+                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr};
+  *out = op;
+  return SLQ_OK;
+}
+
+extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const void *A, int64_t lda,
+                                slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || n >= (int64_t)1 << 31 || !A || lda < n) return fail(SLQ_EINVAL, "bad dense operator shape");
+  HIP_TRY(hipSetDevice(ctx->device));
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr};
+  const size_t es = esize(dtype);
+  hipError_t e = hipMalloc(&op->vals, (size_t)n * n * es);
+  if (e == hipSuccess)
+    e = hipMemcpy2DAsync(op->vals, (size_t)n * es, A, (size_t)lda * es, (size_t)n * es, (size_t)n,
+                         hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "dense upload: %s", hipGetErrorString(e));
+  }
+  *out = op;
+  return SLQ_OK;
+}
+
+extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_matvec_fn fn,
+                                   void *user, slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || n >= (int64_t)1 << 31) return fail(SLQ_EINVAL, "bad operator shape");
+  if (!fn) return fail(SLQ_EINVAL, "Supplied object is missing 'matvec' attribute.");
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user};
+  *out = op;
+  return SLQ_OK;
+}
+
+extern "C" int slq_operator_destroy(slq_operator *op) {
+  if (!op) return SLQ_OK;
+  if (op->owns) {
+    hipSetDevice(op->ctx->device);
+    if (op->rowptr) hipFree(op->rowptr);
+    if (op->colind) hipFree(op->colind);
+    if (op->vals) hipFree(op->vals);
+  }
+  delete op;
+  return SLQ_OK;
+}
+
+extern "C" int slq_operator_shape(const slq_operator *op, int64_t *nrows, int64_t *ncols,
+                                  int64_t *nnz, int *dtype) {
+  if (!op) return fail(SLQ_EINVAL, "op is NULL");
+  if (nrows) *nrows = op->n;
+  if (ncols) *ncols = op->n;
+  if (nnz) *nnz = op->nnz;
+  if (dtype) *dtype = op->dtype;
+  return SLQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// geometry + dispatch
+// ---------------------------------------------------------------------------------------------------
+static void choose_geometry(int dtype, int nprobes, int *LPR, int *PW, int *NP) {
+  const int V = dtype == SLQ_F64 ? 2 : 4;
+  int lpr = 8;
+  while (lpr < 64 && lpr * V < nprobes) lpr *= 2;
+  const int forced = env_int("SLQ_LPR", 0);
+  if (forced == 8 || forced == 16 || forced == 32 || forced == 64) lpr = forced;
+  *LPR = lpr;
+  *PW = lpr * V;
+  *NP = (nprobes + *PW - 1) / *PW;
+}
+
+template <int L> using LprTag = std::integral_constant<int, L>;
+// calls fn(F{}, LprTag<L>{}) for the runtime (dtype, lanes-per-row) pair
+template <typename Fn> static inline void dispatch(int dtype, int lpr, Fn &&fn) {
+  if (dtype == SLQ_F64) {
+    switch (lpr) {
+      case 64: fn(double{}, LprTag<64>{}); break;
+      case 32: fn(double{}, LprTag<32>{}); break;
+      case 16: fn(double{}, LprTag<16>{}); break;
+      default: fn(double{}, LprTag<8>{}); break;
+    }
+  } else {
+    switch (lpr) {
+      case 64: fn(float{}, LprTag<64>{}); break;
+      case 32: fn(float{}, LprTag<32>{}); break;
+      case 16: fn(float{}, LprTag<16>{}); break;
+      default: fn(float{}, LprTag<8>{}); break;
+    }
+  }
+}
+#define DISPATCH(DT, LPRV, BODY)                          \
+  dispatch(DT, LPRV, [&](auto _f, auto _l) {              \
+    using F = decltype(_f);                               \
+    constexpr int L = decltype(_l)::value;                \
+    BODY;                                                 \
+  })
+
+static inline char *slot_ptr(const slq_plan *p, int slot) {
+  return (char *)p->ring + (size_t)slot * (size_t)p->slot_stride * p->esz;
+}
+
+// profiling brackets ----------------------------------------------------------------------------------
+static int prof_begin(slq_plan *p, int kind, ProfEvent *ev) {
+  if (!p->prof) return SLQ_OK;
+  if (!p->pool.empty()) {
+    *ev = p->pool.back();
+    p->pool.pop_back();
+  } else {
+    HIP_TRY(hipEventCreate(&ev->a));
+    HIP_TRY(hipEventCreate(&ev->b));
+  }
+  ev->kind = kind;
+  HIP_TRY(hipEventRecord(ev->a, p->ctx->stream));
+  return SLQ_OK;
+}
+static int prof_end(slq_plan *p, ProfEvent *ev) {
+  if (!p->prof) return SLQ_OK;
+  HIP_TRY(hipEventRecord(ev->b, p->ctx->stream));
+  p->events.push_back(*ev);
+  return SLQ_OK;
+}
+#define PROFILED(plan, kind, launch)        \
+  do {                                      \
+    ProfEvent _ev;                          \
+    SLQ_TRY(prof_begin(plan, kind, &_ev));  \
+    launch;                                 \
+    SLQ_TRY(prof_end(plan, &_ev));          \
+  } while (0)
+
+static int prof_collect(slq_plan *p) {
+  if (p->events.empty()) return SLQ_OK;
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  for (auto &ev : p->events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    p->acc.ms[ev.kind] += ms;
+    p->acc.launches[ev.kind] += 1;
+    p->pool.push_back(ev);
+  }
+  p->events.clear();
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_profile_enable(slq_plan *plan, int enable) {
+  if (!plan) return fail(SLQ_EINVAL, "plan is NULL");
+  SLQ_TRY(prof_collect(plan));
+  plan->prof = enable != 0;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_profile_read(slq_plan *plan, slq_profile *out, int reset) {
+  if (!plan || !out) return fail(SLQ_EINVAL, "plan/out is NULL");
+  HIP_TRY(hipSetDevice(plan->ctx->device));
+  SLQ_TRY(prof_collect(plan));
+  *out = plan->acc;
+  if (reset) memset(&plan->acc, 0, sizeof(plan->acc));
+  return SLQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------
+static int normalise_params(int64_t n, int *deg, int *orth) {
+  if (*deg < 1) return fail(SLQ_EINVAL, "Number of steps must be positive!");
+  if (*deg > n) *deg = (int)n;                                // lanczos.py:79, operators.py:68
+  if (*deg > kMaxDeg) return fail(SLQ_EINVAL, "deg %d exceeds the supported maximum %d", *deg, kMaxDeg);
+  if (*orth < 0 || *orth > *deg) *orth = *deg;                 // lanczos.py:88, operators.py:80
+  return SLQ_OK;
+}
+
+static int ring_slots(int deg, int orth, int keep_basis) {
+  if (keep_basis) return deg + 1;
+  if (orth == 0) return 2;
+  return std::max(orth + 1, 3);
+}
+
+static void grid_sizes(int n, int LPR, int num_cus, int *nblkA, int *nblkS) {
+  const int RPW = 64 / LPR;
+  const int rows_per_block = kWaves * RPW;
+  const int per_cu = std::max(1, env_int("SLQ_BLOCKS_PER_CU", 2));
+  const int cap = std::max(8, num_cus * per_cu);
+  // sweep A: a multiple of 8 blocks (XCD-aware chunking), no more than the rows can feed
+  const int chunk = (n + 7) / 8;
+  int per_xcd = std::min(cap / 8, (chunk + rows_per_block - 1) / rows_per_block);
+  per_xcd = std::max(per_xcd, 1);
+  *nblkA = 8 * per_xcd;
+  int s = std::min(cap, (n + rows_per_block * 4 - 1) / (rows_per_block * 4));
+  *nblkS = std::max(s, 1);
+}
+
+extern "C" int slq_plan_query_bytes(int dtype, int64_t n, int nprobes, int deg, int orth,
+                                    int keep_basis, size_t *bytes) {
+  if (!bytes) return fail(SLQ_EINVAL, "bytes is NULL");
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || nprobes <= 0) return fail(SLQ_EINVAL, "n and nprobes must be positive");
+  SLQ_TRY(normalise_params(n, &deg, &orth));
+  int LPR, PW, NP;
+  choose_geometry(dtype, nprobes, &LPR, &PW, &NP);
+  const size_t S = ring_slots(deg, orth, keep_basis);
+  *bytes = S * (size_t)NP * (size_t)n * PW * esize(dtype);
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_destroy(slq_plan *p) {
+  if (!p) return SLQ_OK;
+  hipSetDevice(p->ctx->device);
+  hipStreamSynchronize(p->ctx->stream);
+  for (auto &ev : p->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+  for (auto &ev : p->pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+  if (p->ring) hipFree(p->ring);
+  if (p->T) hipFree(p->T);
+  if (p->stage) hipFree(p->stage);
+  if (p->scal) hipFree(p->scal);
+  if (p->part) hipFree(p->part);
+  if (p->quad_d) hipFree(p->quad_d);
+  if (p->st.active) hipFree(p->st.active);
+  delete p;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, int deg, int orth,
+                               int keep_basis, slq_plan **out) {
+  if (!ctx || !op || !out) return fail(SLQ_EINVAL, "ctx/op/out is NULL");
+  *out = nullptr;
+  if (op->ctx != ctx) return fail(SLQ_EINVAL, "operator belongs to another context");
+  if (nprobes <= 0) return fail(SLQ_EINVAL, "nprobes must be positive");
+  SLQ_TRY(normalise_params(op->n, &deg, &orth));
+  HIP_TRY(hipSetDevice(ctx->device));
+  slq_plan *p = new (std::nothrow) slq_plan();
+  if (!p) return fail(SLQ_ENOMEM, "host allocation failed");
+  p->ctx = ctx;
+  p->op = op;
+  p->dtype = op->dtype;
+  p->n = (int)op->n;
+  p->nprobes = nprobes;
+  p->deg = deg;
+  p->orth = orth;
+  p->keep_basis = keep_basis != 0;
+  p->esz = esize(op->dtype);
+  choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
+  p->bpad = p->NP * p->PW;
+  p->S = ring_slots(deg, orth, p->keep_basis);
+  p->slot_stride = (int64_t)p->NP * p->n * p->PW;
+  p->rmax = std::max(orth, 1);
+  grid_sizes(p->n, p->LPR, ctx->num_cus, &p->nblkA, &p->nblkS);
+  memset(&p->acc, 0, sizeof(p->acc));
+  memset(&p->st, 0, sizeof(p->st));
+
+  const size_t ring_bytes = (size_t)p->S * (size_t)p->slot_stride * p->esz;
+  const size_t bp = p->bpad;
+  // alpha[deg+1], nu[deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
+  const size_t nscal = ((size_t)(deg + 1) * 2 + 1 + 2 + 1 + (size_t)p->rmax) * bp;
+  const size_t npart = (size_t)std::max(p->nblkA, kReorthChunk * p->nblkS) * bp;
+  hipError_t e = hipMalloc(&p->ring, ring_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->st.active, bp * 2 * sizeof(int) + 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->quad_d, (bp + 2 * bp * (size_t)deg) * 8);
+  if (e == hipSuccess && op->kind != OP_CSR) e = hipMalloc(&p->T, (size_t)p->slot_stride * p->esz);
+  if (e != hipSuccess) {
+    slq_plan_destroy(p);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP,
+                "plan workspace (%zu bytes of Lanczos panels): %s", ring_bytes, hipGetErrorString(e));
+  }
+  p->bytes = ring_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + (p->T ? (size_t)p->slot_stride * p->esz : 0);
+  double *s = p->scal;
+  p->st.alpha = s; s += (size_t)(deg + 1) * bp;
+  p->st.nu = s; s += (size_t)(deg + 1) * bp;
+  p->st.vnorm2 = s; s += bp;
+  p->st.coefA = s; s += 2 * bp;
+  p->st.coefB = s; s += bp;
+  p->st.gamma = s;
+  p->st.steps = p->st.active + bp;
+  p->fail_d = p->st.steps + bp;
+  p->st.bpad = p->bpad;
+  p->st.nprobes = nprobes;
+  p->st.deg = deg;
+  p->nodes_d = p->quad_d + bp;
+  p->weights_d = p->nodes_d + bp * (size_t)deg;
+  *out = p;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_workspace_bytes(const slq_plan *plan, size_t *bytes) {
+  if (!plan || !bytes) return fail(SLQ_EINVAL, "plan/bytes is NULL");
+  *bytes = plan->bytes;
+  return SLQ_OK;
+}
+
+// staging buffer of `cols` column-major columns
+static int ensure_stage(slq_plan *p, int cols) {
+  if (p->stage && p->stage_cols >= cols) return SLQ_OK;
+  if (p->stage) { hipFree(p->stage); p->stage = nullptr; }
+  HIP_TRY(hipMalloc(&p->stage, (size_t)cols * p->n * p->esz));
+  p->stage_cols = cols;
+  return SLQ_OK;
+}
+
+static int stage_chunk_cols(const slq_plan *p) {
+  // ~256 MiB of staging at most
+  const size_t per_col = (size_t)p->n * p->esz;
+  size_t c = std::max<size_t>(1, ((size_t)256 << 20) / per_col);
+  return (int)std::min<size_t>(c, (size_t)p->bpad);
+}
+
+// ||v||^2 of slot 0 -> nu_0, activity, first coefficients
+static int init_from_probes(slq_plan *p, int sphere) {
+  hipStream_t st = p->ctx->stream;
+  dim3 g(p->nblkS, p->NP);
+  PROFILED(p, SLQ_K_AXPY_NORM,
+           DISPATCH(p->dtype, p->LPR,
+                    (k_axpy_norm<F, L, 1><<<g, dim3(kBlock), 0, st>>>(p->n,
+                                        (F *)slot_ptr(p, 0), (const F *)nullptr,
+                                        (const double *)nullptr, p->part, p->bpad))));
+  PROFILED(p, SLQ_K_FINALIZE,
+           hipLaunchKernelGGL(k_fin_init, dim3((p->bpad + 63) / 64), dim3(256), 0, st, p->st, p->part,
+                              p->nblkS, sphere, (double)p->n));
+  HIP_TRY(hipGetLastError());
+  p->probes_ready = true;
+  p->ran = false;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_set_probes(slq_plan *p, const void *X, int64_t ldx) {
+  if (!p || !X) return fail(SLQ_EINVAL, "plan/X is NULL");
+  if (ldx < p->n) return fail(SLQ_EINVAL, "ldx (%lld) < n (%d)", (long long)ldx, p->n);
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int cc = stage_chunk_cols(p);
+  SLQ_TRY(ensure_stage(p, cc));
+  // padding columns must be zero
+  if (p->nprobes < p->bpad)
+    HIP_TRY(hipMemsetAsync(slot_ptr(p, 0), 0, (size_t)p->slot_stride * p->esz, st));
+  for (int c0 = 0; c0 < p->nprobes; c0 += cc) {
+    const int nc = std::min(cc, p->nprobes - c0);
+    const char *src = (const char *)X + (size_t)c0 * (size_t)ldx * p->esz;
+    HIP_TRY(hipMemcpy2DAsync(p->stage, (size_t)p->n * p->esz, src, (size_t)ldx * p->esz,
+                             (size_t)p->n * p->esz, (size_t)nc, hipMemcpyHostToDevice, st));
+    dim3 g((p->n + 63) / 64, (nc + 63) / 64);
+    PROFILED(p, SLQ_K_PROBES, {
+      if (p->dtype == SLQ_F64)
+        hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)slot_ptr(p, 0), p->PW);
+      else
+        hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)slot_ptr(p, 0), p->PW);
+    });
+    HIP_TRY(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
+  }
+  p->pdf_sphere = 0;
+  return init_from_probes(p, 0);
+}
+
+extern "C" int slq_plan_generate_probes(slq_plan *p, int pdf, uint64_t seed, uint64_t probe_offset) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (pdf < 0 || pdf > 2) return fail(SLQ_EINVAL, "Invalid distribution id %d supplied.", pdf);
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int RPW = 64 / p->LPR;
+  const int items = (p->n + (pdf == 0 ? 127 : 1)) / (pdf == 0 ? 128 : 2);
+  const int gx = std::max(1, std::min(p->ctx->num_cus * 8, (items + 4 * RPW - 1) / (4 * RPW)));
+  dim3 g(gx, p->NP);
+  PROFILED(p, SLQ_K_PROBES,
+           DISPATCH(p->dtype, p->LPR,
+                    (k_gen_probes<F, L><<<g, dim3(256), 0, st>>>(p->n,
+                                        (F *)slot_ptr(p, 0), pdf, seed, probe_offset, p->nprobes))));
+  p->pdf_sphere = (pdf == SLQ_PDF_SPHERE);
+  return init_from_probes(p, p->pdf_sphere);
+}
+
+// copy columns [c0, c0+nc) of `slot` to a host column-major array, optional per-column scale
+static int panel_to_host(slq_plan *p, int slot, int c0, int nc, void *X, int64_t ldx,
+                         const double *d_scale) {
+  hipStream_t st = p->ctx->stream;
+  const int cc = stage_chunk_cols(p);
+  SLQ_TRY(ensure_stage(p, cc));
+  for (int o = 0; o < nc; o += cc) {
+    const int m = std::min(cc, nc - o);
+    dim3 g((p->n + 63) / 64, (m + 63) / 64);
+    if (p->dtype == SLQ_F64)
+      hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, slot), c0 + o, m, (double *)p->stage, p->PW, d_scale);
+    else
+      hipLaunchKernelGGL(k_panel_to_cols<float>, g, dim3(256), 0, st, p->n, (const float *)slot_ptr(p, slot), c0 + o, m, (float *)p->stage, p->PW, d_scale);
+    HIP_TRY(hipMemcpy2DAsync((char *)X + (size_t)o * (size_t)ldx * p->esz, (size_t)ldx * p->esz, p->stage,
+                             (size_t)p->n * p->esz, (size_t)p->n * p->esz, (size_t)m, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_get_probes(slq_plan *p, void *X, int64_t ldx) {
+  if (!p || !X) return fail(SLQ_EINVAL, "plan/X is NULL");
+  if (!p->probes_ready) return fail(SLQ_EINVAL, "no probes set, or they were consumed by a run");
+  if (ldx < p->n) return fail(SLQ_EINVAL, "ldx < n");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  return panel_to_host(p, 0, 0, p->nprobes, X, ldx, nullptr);
+}
+
+// T = A * (slot c), unscaled, for operators without a fused kernel
+static int apply_operator_unfused(slq_plan *p, int slot_c) {
+  hipStream_t st = p->ctx->stream;
+  slq_operator *op = p->op;
+  if (op->kind == OP_DENSE) {
+    dim3 g(std::max(1, std::min(p->ctx->num_cus * 2, (p->n + kWaves - 1) / kWaves)), p->NP);
+    PROFILED(p, SLQ_K_SPMM,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_dense_panel<F, L><<<g, dim3(kBlock), 0, st>>>(p->n,
+                                          (const F *)op->vals, op->lda, (const F *)slot_ptr(p, slot_c), (F *)p->T))));
+    return SLQ_OK;
+  }
+  // host callback: device -> host, one matvec per probe, host -> device
+  const size_t colb = (size_t)p->n * p->esz;
+  if (p->hbuf.size() < 2 * colb * (size_t)p->nprobes) p->hbuf.resize(2 * colb * (size_t)p->nprobes);
+  char *hx = p->hbuf.data(), *hy = hx + colb * p->nprobes;
+  SLQ_TRY(panel_to_host(p, slot_c, 0, p->nprobes, hx, p->n, nullptr));
+  for (int i = 0; i < p->nprobes; ++i)
+    if (op->fn(op->user, hx + colb * i, hy + colb * i) != 0)
+      return fail(SLQ_ECALLBACK, "operator callback failed on probe %d", i);
+  const int cc = stage_chunk_cols(p);
+  HIP_TRY(hipMemsetAsync(p->T, 0, (size_t)p->slot_stride * p->esz, st));
+  for (int c0 = 0; c0 < p->nprobes; c0 += cc) {
+    const int nc = std::min(cc, p->nprobes - c0);
+    HIP_TRY(hipMemcpyAsync(p->stage, hy + colb * c0, colb * nc, hipMemcpyHostToDevice, st));
+    dim3 g((p->n + 63) / 64, (nc + 63) / 64);
+    if (p->dtype == SLQ_F64)
+      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)p->T, p->PW);
+    else
+      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)p->T, p->PW);
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_run(slq_plan *p, double rtol) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int bp = p->bpad, deg = p->deg, S = p->S;
+  const double eps = p->dtype == SLQ_F64 ? std::numeric_limits<double>::epsilon()
+                                         : (double)std::numeric_limits<float>::epsilon();
+  const double residual_tol = std::sqrt((double)p->n) * rtol;   // lanczos.h:110
+  const double orth_tol = 2.0 * eps * std::sqrt((double)p->n);  // lanczos.h:53
+  // alpha and nu[1..] start from zero (the reference's fresh np.zeros buffers, lanczos.py:101-102)
+  HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
+  HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
+  const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gF((bp + 63) / 64);
+  const slq_operator *op = p->op;
+  for (int j = 0; j < deg; ++j) {
+    const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
+    const int first = (j == 0);
+    if (op->kind == OP_CSR) {
+      PROFILED(p, SLQ_K_SPMM,
+               DISPATCH(p->dtype, p->LPR,
+                        (k_spmm_3term<F, L><<<gA, dim3(kBlock), 0, st>>>(p->n,
+                                            op->rowptr, op->colind, (const F *)op->vals,
+                                            (const F *)slot_ptr(p, sc_), (const F *)slot_ptr(p, sp_),
+                                            (F *)slot_ptr(p, sn_), p->st.coefA, p->part, bp, first))));
+      PROFILED(p, SLQ_K_FINALIZE,
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(256), 0, st, p->st, p->part, p->nblkA, j));
+    } else {
+      SLQ_TRY(apply_operator_unfused(p, sc_));
+      PROFILED(p, SLQ_K_AXPY_NORM,
+               DISPATCH(p->dtype, p->LPR,
+                        (k_3term<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                                            (const F *)p->T, (const F *)slot_ptr(p, sc_),
+                                            (const F *)slot_ptr(p, sp_), (F *)slot_ptr(p, sn_),
+                                            p->st.coefA, p->part, bp, first))));
+      PROFILED(p, SLQ_K_FINALIZE,
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(256), 0, st, p->st, p->part, p->nblkS, j));
+    }
+    const int r = p->orth > 0 ? std::min(j + 1, p->orth) : 0;
+    if (r == 0) {
+      PROFILED(p, SLQ_K_AXPY_NORM,
+               DISPATCH(p->dtype, p->LPR,
+                        (k_axpy_norm<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                                            (F *)slot_ptr(p, sn_), (const F *)slot_ptr(p, sc_),
+                                            p->st.coefB, p->part, bp))));
+    } else {
+      for (int i0 = 0; i0 < r; i0 += kReorthChunk) {
+        const int rc = std::min(kReorthChunk, r - i0);
+        PROFILED(p, SLQ_K_REORTH_DOT,
+                 DISPATCH(p->dtype, p->LPR,
+                          (k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                                              (F *)p->ring, p->slot_stride, S, j, i0, rc, (int)(i0 == 0),
+                                              p->st.coefB, p->part, bp))));
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(256), 0, st, p->st,
+                                    p->part, p->nblkS, j, i0, orth_tol));
+      }
+      const int V = p->dtype == SLQ_F64 ? 2 : 4;
+      // gamma for up to kUpdChunk columns is staged in LDS per launch (<= 160 KiB per workgroup)
+      const int kUpdChunk = (int)((150 * 1024 - sizeof(double) * kWaves * 64 * V) / ((size_t)p->PW * p->esz));
+      for (int i0 = 0; i0 < r; i0 += kUpdChunk) {
+        const int rc = std::min(kUpdChunk, r - i0);
+        const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
+        if (lds > 48 * 1024) {
+          hipError_t ae = hipSuccess;
+          DISPATCH(p->dtype, p->LPR,
+                   ae = hipFuncSetAttribute((const void *)k_reorth_update<F, L>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIP_TRY(ae);
+        }
+        PROFILED(p, SLQ_K_REORTH_UPD,
+                 DISPATCH(p->dtype, p->LPR,
+                          (k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(
+                              p->n, (F *)p->ring, p->slot_stride, S, j, i0, rc,
+                              p->st.gamma + (size_t)i0 * bp, p->part, bp))));
+      }
+    }
+    PROFILED(p, SLQ_K_FINALIZE,
+             hipLaunchKernelGGL(k_fin_beta, gF, dim3(256), 0, st, p->st, p->part, p->nblkS, j, residual_tol));
+  }
+  HIP_TRY(hipGetLastError());
+  p->probes_ready = false;
+  p->ran = true;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_get_tridiag(slq_plan *p, void *alpha, void *beta, int32_t *steps) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (!p->ran) return fail(SLQ_EINVAL, "slq_plan_get_tridiag: no completed run");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int bp = p->bpad, deg = p->deg, P = p->nprobes;
+  std::vector<double> ha((size_t)(deg + 1) * bp), hn((size_t)(deg + 1) * bp);
+  std::vector<int> hs(bp);
+  HIP_TRY(hipMemcpyAsync(ha.data(), p->st.alpha, ha.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hn.data(), p->st.nu, hn.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hs.data(), p->st.steps, (size_t)bp * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < P; ++i) {
+    for (int t = 0; t <= deg; ++t) {
+      const double a = ha[(size_t)t * bp + i];
+      const double b = (t == 0) ? 0.0 : hn[(size_t)t * bp + i];  // beta[0] = 0 (lanczos.h:121)
+      if (p->dtype == SLQ_F64) {
+        if (alpha) ((double *)alpha)[(size_t)i * (deg + 1) + t] = a;
+        if (beta) ((double *)beta)[(size_t)i * (deg + 1) + t] = b;
+      } else {
+        if (alpha) ((float *)alpha)[(size_t)i * (deg + 1) + t] = (float)a;
+        if (beta) ((float *)beta)[(size_t)i * (deg + 1) + t] = (float)b;
+      }
+    }
+    if (steps) steps[i] = hs[i];
+  }
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_quadrature(slq_plan *p, int fun_id, const double *fun_params, double *quad,
+                                   double *nodes, double *weights) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (!p->ran) return fail(SLQ_EINVAL, "slq_plan_quadrature: no completed run");
+  if (fun_id < SLQ_FUN_NONE || fun_id > SLQ_FUN_SOFTSIGN) return fail(SLQ_EINVAL, "Unknown function id %d.", fun_id);
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int deg = p->deg, P = p->nprobes;
+  const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
+  const size_t lds = (size_t)3 * deg * 64 * 8;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    HIP_TRY(hipFuncSetAttribute((const void *)k_quadrature, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip tridiagonal solver", deg);
+  HIP_TRY(hipMemsetAsync(p->fail_d, 0, sizeof(int), st));
+  PROFILED(p, SLQ_K_QUADRATURE,
+           hipLaunchKernelGGL(k_quadrature, dim3((P + 63) / 64), dim3(64), lds, st, p->st, fun_id, p0, p1,
+                              p->quad_d, (nodes ? p->nodes_d : nullptr), (weights ? p->weights_d : nullptr), p->fail_d));
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (quad) HIP_TRY(hipMemcpyAsync(quad, p->quad_d, (size_t)P * 8, hipMemcpyDeviceToHost, st));
+  if (nodes) HIP_TRY(hipMemcpyAsync(nodes, p->nodes_d, (size_t)P * deg * 8, hipMemcpyDeviceToHost, st));
+  if (weights) HIP_TRY(hipMemcpyAsync(weights, p->weights_d, (size_t)P * deg * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_get_basis(slq_plan *p, int probe, void *Q, int64_t ldq) {
+  if (!p || !Q) return fail(SLQ_EINVAL, "plan/Q is NULL");
+  if (!p->keep_basis) return fail(SLQ_EINVAL, "plan was created without keep_basis");
+  if (!p->ran) return fail(SLQ_EINVAL, "no completed run");
+  if (probe < 0 || probe >= p->nprobes || ldq < p->n) return fail(SLQ_EINVAL, "bad probe index or ldq");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int bp = p->bpad, deg = p->deg;
+  std::vector<double> hn((size_t)(deg + 1) * bp), hscale((size_t)deg * bp, 0.0);
+  HIP_TRY(hipMemcpyAsync(hn.data(), p->st.nu, hn.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int t = 0; t < deg; ++t) {
+    const double nu = hn[(size_t)t * bp + probe];
+    hscale[(size_t)t * bp + probe] = nu > 0.0 ? 1.0 / nu : 0.0;
+  }
+  double *dscale = nullptr;
+  HIP_TRY(hipMalloc((void **)&dscale, hscale.size() * 8));
+  hipError_t e = hipMemcpyAsync(dscale, hscale.data(), hscale.size() * 8, hipMemcpyHostToDevice, st);
+  int rc = e == hipSuccess ? SLQ_OK : fail(SLQ_EHIP, "scale upload: %s", hipGetErrorString(e));
+  for (int t = 0; t < deg && rc == SLQ_OK; ++t)
+    rc = panel_to_host(p, t, probe, 1, (char *)Q + (size_t)t * (size_t)ldq * p->esz, ldq, dscale + (size_t)t * bp);
+  hipFree(dscale);
+  return rc;
+}
+
+extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_params, void *Y, int64_t ldy) {
+  (void)fun_id; (void)fun_params; (void)Y; (void)ldy;
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  return fail(SLQ_EINVAL, "slq_plan_fun_action: the f(A)v action (SURVEY.md §8 row f1) is not implemented yet");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stand-alone operator product
+// ---------------------------------------------------------------------------------------------------
+extern "C" int slq_operator_matmat(slq_operator *op, const void *X, int64_t ldx, void *Y, int64_t ldy, int b) {
+  if (!op || !X || !Y || b <= 0) return fail(SLQ_EINVAL, "bad arguments");
+  if (ldx < op->n || ldy < op->n) return fail(SLQ_EINVAL, "leading dimension < n");
+  slq_plan *p = nullptr;
+  // a keep_basis plan with deg = 1 gives two slots: 0 = X, 1 = Y
+  SLQ_TRY(slq_plan_create(op->ctx, op, b, 1, 0, 1, &p));
+  hipStream_t st = op->ctx->stream;
+  int rc = slq_plan_set_probes(p, X, ldx);
+  if (rc == SLQ_OK) {
+    if (op->kind == OP_CSR) {
+      dim3 g(p->nblkS, p->NP);
+      DISPATCH(p->dtype, p->LPR,
+               (k_spmm_plain<F, L><<<g, dim3(kBlock), 0, st>>>(p->n, op->rowptr, op->colind,
+                                   (const F *)op->vals, (const F *)slot_ptr(p, 0), (F *)slot_ptr(p, 1))));
+    } else {
+      rc = apply_operator_unfused(p, 0);
+      if (rc == SLQ_OK) {
+        hipError_t e = hipMemcpyAsync(slot_ptr(p, 1), p->T, (size_t)p->slot_stride * p->esz, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = fail(SLQ_EHIP, "copy: %s", hipGetErrorString(e));
+      }
+    }
+  }
+  if (rc == SLQ_OK) rc = panel_to_host(p, 1, 0, b, Y, ldy, nullptr);
+  slq_plan_destroy(p);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one-shot entries
+// ---------------------------------------------------------------------------------------------------
+extern "C" int slq_quad_batch(slq_context *ctx, slq_operator *op, const void *X, int64_t ldx, int pdf,
+                              uint64_t seed, uint64_t probe_offset, int nprobes, int deg, double rtol,
+                              int orth, int fun_id, const double *fun_params, double *quad_out,
+                              double *nodes_out, double *weights_out) {
+  if (!ctx || !op) return fail(SLQ_EINVAL, "ctx/op is NULL");
+  if (nprobes <= 0) return fail(SLQ_EINVAL, "nprobes must be positive");
+  int d = deg, o = orth;
+  SLQ_TRY(normalise_params(op->n, &d, &o));
+  // size the probe chunk to the free device memory (all probes at once when they fit)
+  size_t free_b = 0, total_b = 0;
+  SLQ_TRY(slq_context_meminfo(ctx, &free_b, &total_b));
+  int chunk = nprobes;
+  for (;;) {
+    size_t need = 0;
+    SLQ_TRY(slq_plan_query_bytes(op->dtype, op->n, chunk, d, o, 0, &need));
+    if (need + ((size_t)1 << 30) <= free_b || chunk <= 8) break;
+    chunk = (chunk + 1) / 2;
+  }
+  int rc = SLQ_OK;
+  for (int c0 = 0; c0 < nprobes && rc == SLQ_OK; c0 += chunk) {
+    const int nc = std::min(chunk, nprobes - c0);
+    slq_plan *p = nullptr;
+    rc = slq_plan_create(ctx, op, nc, d, o, 0, &p);
+    if (rc != SLQ_OK) break;
+    if (X)
+      rc = slq_plan_set_probes(p, (const char *)X + (size_t)c0 * (size_t)ldx * esize(op->dtype), ldx);
+    else
+      rc = slq_plan_generate_probes(p, pdf, seed, probe_offset + (uint64_t)c0);
+    if (rc == SLQ_OK) rc = slq_plan_run(p, rtol);
+    if (rc == SLQ_OK)
+      rc = slq_plan_quadrature(p, fun_id, fun_params, quad_out ? quad_out + c0 : nullptr,
+                               nodes_out ? nodes_out + (size_t)c0 * d : nullptr,
+                               weights_out ? weights_out + (size_t)c0 * d : nullptr);
+    slq_plan_destroy(p);
+  }
+  return rc;
+}
+
+template <typename F>
+static int lanczos_single(slq_context *ctx, slq_operator *op, F *v, int deg, F rtol, int orth, F *alpha,
+                          F *beta, F *Q, size_t ncv) {
+  if (!ctx || !op || !v || !alpha || !beta || !Q) return fail(SLQ_EINVAL, "NULL argument");
+  if (op->dtype != (sizeof(F) == 8 ? SLQ_F64 : SLQ_F32)) return fail(SLQ_EINVAL, "operator dtype does not match the entry point");
+  if (deg < 1) return fail(SLQ_EINVAL, "Number of steps must be positive!");
+  if (deg > op->n) return fail(SLQ_EINVAL, "deg exceeds the operator dimension");
+  // precondition of the reference kernel (lanczos.h:91): orth < ncv <= deg is NOT enforced there;
+  // what it needs to be well defined is 2 <= ncv and orth <= ncv
+  if (ncv < 2 || (size_t)std::max(orth, 0) > ncv) return fail(SLQ_EINVAL, "need ncv >= 2 and orth <= ncv (ncv=%zu, orth=%d)", ncv, orth);
+  if (orth < 0) return fail(SLQ_EINVAL, "orth must be non-negative at the native boundary");
+  const int n = (int)op->n;
+  const bool keep = true;
+  slq_plan *p = nullptr;
+  SLQ_TRY(slq_plan_create(ctx, op, 1, deg, orth, keep, &p));
+  int rc = slq_plan_set_probes(p, v, n);
+  if (rc == SLQ_OK) rc = slq_plan_run(p, (double)rtol);
+  std::vector<F> a(deg + 1), b(deg + 1);
+  int32_t steps = 0;
+  if (rc == SLQ_OK) rc = slq_plan_get_tridiag(p, a.data(), b.data(), &steps);
+  if (rc == SLQ_OK) {
+    // the reference writes alpha[0..steps) and beta[0..steps]; later entries keep the caller's values
+    for (int t = 0; t < steps; ++t) alpha[t] = a[t];
+    for (int t = 0; t <= steps; ++t) beta[t] = b[t];
+    // ring columns: Lanczos vector t sits in column t % ncv; the last write wins (lanczos.h:143-147).
+    // Vectors 0..steps-1 are written (vector `steps` is never normalised into the ring, :140-142).
+    std::vector<F> Qfull((size_t)n * deg);
+    rc = slq_plan_get_basis(p, 0, Qfull.data(), n);
+    if (rc == SLQ_OK) {
+      // column ncv-1 is zeroed on entry (lanczos.h:119) unless a later vector lands there
+      memset(Q + (size_t)(ncv - 1) * n, 0, (size_t)n * sizeof(F));
+      for (int t = 0; t < steps; ++t) memcpy(Q + (size_t)(t % ncv) * n, Qfull.data() + (size_t)t * n, (size_t)n * sizeof(F));
+    }
+    // v is scratch in the reference and ends as the last unnormalised residual; give it back
+    if (rc == SLQ_OK) {
+      const int slot = steps % p->S;
+      rc = panel_to_host(p, slot, 0, 1, v, n, nullptr);
+    }
+  }
+  slq_plan_destroy(p);
+  return rc == SLQ_OK ? steps : rc;
+}
+
+extern "C" int slq_lanczos_f64(slq_context *ctx, slq_operator *op, double *v, int deg, double rtol, int orth,
+                               double *alpha, double *beta, double *Q, size_t ncv) {
+  return lanczos_single<double>(ctx, op, v, deg, rtol, orth, alpha, beta, Q, ncv);
+}
+extern "C" int slq_lanczos_f32(slq_context *ctx, slq_operator *op, float *v, int deg, float rtol, int orth,
+                               float *alpha, float *beta, float *Q, size_t ncv) {
+  return lanczos_single<float>(ctx, op, v, deg, rtol, orth, alpha, beta, Q, ncv);
+}

@@ -1,0 +1,779 @@
+// slq_kernels.hpp — hand-written CDNA4 (gfx950) kernels of the SLQ engine.
+//
+// Data layout. P probes advance in lock-step. Vectors are stored as PANELS:
+// panel p of Lanczos vector t is a row-major n x PW array (PW probes per row, PW*sizeof(F) bytes
+// = 256 B..1 KiB contiguous), so that
+//   * the SpMM gather of x[col, :] is one coalesced 16 B/lane wave load serving PW probes,
+//   * every per-probe reduction (alpha = q.w, ||w||^2, Q^T w) is a COLUMN sum: a lane owns its
+//     V = 16/sizeof(F) probe columns for the whole kernel and accumulates in registers; there is
+//     no cross-lane traffic in the inner loops. Cross-wave/cross-block sums go through LDS and a
+//     fixed-order two-stage reduction (bitwise reproducible; no float atomics).
+// A wave covers RPW = 64/LPR rows per instruction, LPR = PW/V lanes per row.
+//
+// Lanczos vectors are kept UNNORMALISED: slot t holds w_t with q_t = w_t / nu_t
+// (nu_0 = ||v||, nu_t = beta_t). The reference's normalisation pass (lanczos.h:143) is folded
+// into per-probe scalar coefficients, which removes one read and one write of n x P per step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slq {
+
+template <typename F> struct VecT;
+template <> struct VecT<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+  static constexpr int V = 2;
+};
+template <> struct VecT<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+  static constexpr int V = 4;
+};
+
+constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
+constexpr int kWaves = kBlock / 64;
+constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
+constexpr int kMaxDeg = 512;         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
+
+template <typename F, int LPR> struct Geo {
+  static constexpr int V = VecT<F>::V;
+  static constexpr int PW = LPR * V;   // probes per panel row
+  static constexpr int RPW = 64 / LPR; // rows per wave instruction
+};
+
+// ---- block-level column reduction -------------------------------------------------------------
+// Every lane holds V partial sums for its V columns (column = (lane % LPR) * V + v). Sum them over
+// the RPW row groups of each wave and over the waves of the block in a fixed order and let thread
+// t < PW write column t of out[] (stride 1).
+template <typename F, int LPR>
+__device__ __forceinline__ void block_reduce_columns(const typename VecT<F>::type &acc,
+                                                     double *red /* kWaves*64*V doubles */,
+                                                     double *out) {
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < V; ++v) red[(wave * 64 + lane) * V + v] = (double)acc[v];
+  __syncthreads();
+  if ((int)threadIdx.x < PW) {
+    const int t = threadIdx.x, cl = t / V, v = t % V;
+    double s = 0.0;
+    for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+      for (int g = 0; g < RPW; ++g) s += red[(w * 64 + g * LPR + cl) * V + v];
+    out[t] = s;
+  }
+  __syncthreads();
+}
+
+// ---- sweep A: panel SpMM + three-term update + alpha partials ----------------------------------
+// For every row i and probe column c of the panel:
+//   w[i,c]      = sc[c] * sum_k A[i,k] * Wc[k,c]  -  cp[c] * Wp[i,c]
+//   partA[c]   += (sc[c] * Wc[i,c]) * w[i,c]
+// i.e. w = A q_c - beta_j q_p and alpha_j = q_c . w   (reference: lanczos.h:127-129), with
+// q_c = sc * Wc (sc = 1/nu_j) and beta_j q_p = cp * Wp (cp = beta_j / nu_{j-1}).
+// Wn may alias Wp (orth = 0 ring of two slots): each element is read then written by the same
+// lane. Row -> wave mapping is XCD-aware: blocks with equal (blockIdx.x % 8) share an XCD's L2
+// (observed round-robin dispatch; speed only), so XCD x sweeps the contiguous row range
+// [x*n/8, (x+1)*n/8) with all of its waves interleaved row by row: the set of rows in flight is a
+// narrow band whose stencil neighbours stay L2-resident, and each panel row is fetched from HBM
+// about once per XCD.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_spmm_3term(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+    const F *__restrict__ vals, const F *Wc, const F *Wp, F *Wn, const double *__restrict__ coefA,
+    double *__restrict__ partA, int bpad, int first) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const F *wc = Wc + poff;
+  const F *wp = Wp + poff;
+  F *wn = Wn + poff;
+  const int colbase = panel * PW + cl * V;
+  VF sc, cp;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    sc[v] = (F)coefA[colbase + v];
+    cp[v] = (F)coefA[bpad + colbase + v];
+  }
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
+  const int chunk = (n + 7) / 8;
+  const int r_begin = xcd * chunk;
+  const int r_end = min(n, r_begin + chunk);
+  const int stride = nbl * kWaves * RPW;
+  VF aacc = (VF)(F)0;
+  for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
+    int row = r0 + g;
+    if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+    if (row < r_end) {
+      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+      VF acc = (VF)(F)0;
+      int p = p0;
+      for (; p + 4 <= p1; p += 4) {
+        const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
+        const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
+        const VF x0 = *(const VF *)(wc + (int64_t)c0 * PW);
+        const VF x1 = *(const VF *)(wc + (int64_t)c1 * PW);
+        const VF x2 = *(const VF *)(wc + (int64_t)c2 * PW);
+        const VF x3 = *(const VF *)(wc + (int64_t)c3 * PW);
+        acc += a0 * x0;
+        acc += a1 * x1;
+        acc += a2 * x2;
+        acc += a3 * x3;
+      }
+      for (; p < p1; ++p) {
+        const int c = colind[p];
+        const F a = vals[p];
+        acc += a * *(const VF *)(wc + (int64_t)c * PW);
+      }
+      const int64_t ro = (int64_t)row * PW;
+      const VF xc = *(const VF *)(wc + ro);
+      VF w = sc * acc;
+      if (!first) w -= cp * *(const VF *)(wp + ro);
+      aacc += (sc * xc) * w;
+      *(VF *)(wn + ro) = w;
+    }
+  }
+  block_reduce_columns<F, LPR>(aacc, red, partA + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- plain panel SpMM: Y = A X (operator plugin surface; also the dense/CSR matmat entry) -------
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_spmm_plain(int n, const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ colind,
+                                                       const F *__restrict__ vals,
+                                                       const F *__restrict__ X, F *__restrict__ Y) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int64_t poff = (int64_t)blockIdx.y * n * PW + cl * V;
+  const F *x = X + poff;
+  F *y = Y + poff;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW; r0 < n; r0 += stride) {
+    const int row = r0 + g;
+    if (row < n) {
+      VF acc = (VF)(F)0;
+      for (int p = rowptr[row]; p < rowptr[row + 1]; ++p)
+        acc += vals[p] * *(const VF *)(x + (int64_t)colind[p] * PW);
+      *(VF *)(y + (int64_t)row * PW) = acc;
+    }
+  }
+}
+
+// Dense symmetric operator, column-major with leading dimension lda: Y[i,:] = sum_k A[k,i] X[k,:]
+// (A symmetric, so row i is read as the contiguous column i). One wave per RPW rows.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_dense_panel(int n, const F *__restrict__ A,
+                                                        int64_t lda, const F *__restrict__ X,
+                                                        F *__restrict__ Y) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int64_t poff = (int64_t)blockIdx.y * n * PW + cl * V;
+  const F *x = X + poff;
+  F *y = Y + poff;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW; r0 < n; r0 += stride) {
+    const int row = r0 + g;
+    if (row < n) {
+      const F *a = A + (int64_t)row * lda;
+      VF acc = (VF)(F)0;
+      int k = 0;
+      for (; k + 4 <= n; k += 4) {
+        const F a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
+        const VF x0 = *(const VF *)(x + (int64_t)k * PW);
+        const VF x1 = *(const VF *)(x + (int64_t)(k + 1) * PW);
+        const VF x2 = *(const VF *)(x + (int64_t)(k + 2) * PW);
+        const VF x3 = *(const VF *)(x + (int64_t)(k + 3) * PW);
+        acc += a0 * x0;
+        acc += a1 * x1;
+        acc += a2 * x2;
+        acc += a3 * x3;
+      }
+      for (; k < n; ++k) acc += a[k] * *(const VF *)(x + (int64_t)k * PW);
+      *(VF *)(y + (int64_t)row * PW) = acc;
+    }
+  }
+}
+
+// Three-term epilogue for operators whose product is computed by a separate kernel (dense,
+// host callback): in: T = A (Wc) unscaled. w = sc*T - cp*Wp ; partA += (sc*Wc) * w ; Wn = w.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_3term(int n, const F *T, const F *Wc, const F *Wp,
+                                                  F *Wn, const double *__restrict__ coefA,
+                                                  double *__restrict__ partA, int bpad,
+                                                  int first) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int colbase = panel * PW + cl * V;
+  VF sc, cp;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    sc[v] = (F)coefA[colbase + v];
+    cp[v] = (F)coefA[bpad + colbase + v];
+  }
+  VF aacc = (VF)(F)0;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW; r0 < n; r0 += stride) {
+    const int row = r0 + g;
+    if (row < n) {
+      const int64_t ro = poff + (int64_t)row * PW;
+      VF w = sc * *(const VF *)(T + ro);
+      if (!first) w -= cp * *(const VF *)(Wp + ro);
+      aacc += (sc * *(const VF *)(Wc + ro)) * w;
+      *(VF *)(Wn + ro) = w;
+    }
+  }
+  block_reduce_columns<F, LPR>(aacc, red, partA + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- sweep B (orth = 0): w -= cB * Wc ; partN += w^2 --------------------------------------------
+// (reference: lanczos.h:130,139 — v -= alpha q_c ; beta = ||v||, with cB = alpha / nu_j.)
+// mode 0: as above.  mode 1: norm only (no update; used for ||v||^2 of the probes).
+template <typename F, int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
+                                                      const double *__restrict__ coefB,
+                                                      double *__restrict__ partN, int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  constexpr int UR = 4;
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int colbase = panel * PW + cl * V;
+  VF cb = (VF)(F)0;
+  if (MODE == 0) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) cb[v] = (F)coefB[colbase + v];
+  }
+  VF nacc = (VF)(F)0;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW + g; r0 < n; r0 += UR * stride) {
+    VF w[UR], q[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = r0 + u * stride;
+      if (row < n) {
+        const int64_t ro = poff + (int64_t)row * PW;
+        w[u] = *(const VF *)(W + ro);
+        if (MODE == 0) q[u] = *(const VF *)(Wc + ro);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = r0 + u * stride;
+      if (row < n) {
+        VF x = w[u];
+        if (MODE == 0) {
+          x -= cb * q[u];
+          *(VF *)(W + poff + (int64_t)row * PW) = x;
+        }
+        nacc += x * x;
+      }
+    }
+  }
+  block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- sweep B (orth > 0): w -= cB*Wc (first chunk only) ; partD[i] += W_{t_i} . w -----------------
+// The reorthogonalisation set is the last r ring vectors t_i = j - i, i = 0..r-1 (reference:
+// orth_vector(v, Q, c, orth, reverse=true), lanczos.h:135 with :58). The reference runs modified
+// Gram-Schmidt (r sequentially dependent dot+axpy passes, lanczos.h:58-65); here all r dots are
+// taken against the same w in ONE pass (block classical Gram-Schmidt as the second
+// orthogonalisation pass after the three-term step), r_chunk <= kReorthChunk columns per launch
+// so the accumulators stay in registers.
+// ring: base of slot 0; vector t lives in slot t % S; slot stride = NP*n*PW elements.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_reorth_dot(
+    int n, F *ring, int64_t slot_stride, int S, int j, int i0, int rc, int apply_axpy,
+    const double *__restrict__ coefB, double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int colbase = panel * PW + cl * V;
+  F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *Wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *U0 = ring + poff;
+  VF cb = (VF)(F)0;
+  if (apply_axpy) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) cb[v] = (F)coefB[colbase + v];
+  }
+  VF dacc[kReorthChunk];
+#pragma unroll
+  for (int i = 0; i < kReorthChunk; ++i) dacc[i] = (VF)(F)0;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int row = (blockIdx.x * kWaves + wave) * RPW + g; row < n; row += stride) {
+    const int64_t ro = (int64_t)row * PW;
+    VF w = *(const VF *)(W + ro);
+    if (apply_axpy) {
+      w -= cb * *(const VF *)(Wc + ro);
+      *(VF *)(W + ro) = w;
+    }
+    VF u[kReorthChunk];
+#pragma unroll
+    for (int i = 0; i < kReorthChunk; ++i)
+      if (i < rc) u[i] = *(const VF *)(U0 + (int64_t)((j - i0 - i) % S) * slot_stride + ro);
+#pragma unroll
+    for (int i = 0; i < kReorthChunk; ++i)
+      if (i < rc) dacc[i] += u[i] * w;
+  }
+  const int64_t nblk = gridDim.x;
+#pragma unroll
+  for (int i = 0; i < kReorthChunk; ++i)
+    if (i < rc)
+      block_reduce_columns<F, LPR>(dacc[i], red,
+                                   partD + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+}
+
+// ---- sweep C: w -= sum_i gamma_i * W_{t_i} ; partN += w^2 ----------------------------------------
+// gamma[i][col] (coefficient on the UNNORMALISED ring vector; zero where the reference's skip
+// thresholds apply, lanczos.h:62) is staged in LDS once per block: r * PW doubles.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_reorth_update(
+    int n, F *ring, int64_t slot_stride, int S, int j, int i0, int r,
+    const double *__restrict__ gamma /* [r][bpad], already offset to column i0 */,
+    double *__restrict__ partN, int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  constexpr int UR = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double *red = (double *)lds_raw;                       // kWaves*64*V doubles
+  F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V); // r * PW
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  for (int t = threadIdx.x; t < r * PW; t += kBlock)
+    gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+  __syncthreads();
+  F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *U0 = ring + poff;
+  VF nacc = (VF)(F)0;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW + g; r0 < n; r0 += UR * stride) {
+    VF w[UR];
+    int64_t ro[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = r0 + u * stride;
+      ro[u] = (int64_t)(row < n ? row : 0) * PW;
+      w[u] = *(const VF *)(W + ro[u]);
+    }
+    for (int i = 0; i < r; ++i) {
+      const F *U = U0 + (int64_t)((j - i0 - i) % S) * slot_stride;
+      const VF gm = *(const VF *)(gl + i * PW + cl * V);
+      VF x[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) x[u] = *(const VF *)(U + ro[u]);
+#pragma unroll
+      for (int u = 0; u < UR; ++u) w[u] -= gm * x[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = r0 + u * stride;
+      if (row < n) {
+        *(VF *)(W + ro[u]) = w[u];
+        nacc += w[u] * w[u];
+      }
+    }
+  }
+  block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- per-step scalar kernels ("finalize"): partials -> alpha / beta / next coefficients ---------
+struct StepState {
+  double *alpha;   // [deg+1][bpad]
+  double *nu;      // [deg+1][bpad]  nu[0] = ||v||, nu[t] = beta_t
+  double *vnorm2;  // [bpad]        ||v||^2 used in the final scaling
+  double *coefA;   // [2][bpad]     sc, cp for the next sweep A
+  double *coefB;   // [bpad]        cB for sweep B
+  double *gamma;   // [rmax][bpad]
+  int *active;     // [bpad]
+  int *steps;      // [bpad]
+  int bpad, nprobes, deg;
+};
+
+// Sum part[blk][col] over blk in a fixed order. Block = 256 threads = 64 columns x 4 slices.
+__device__ __forceinline__ double sum_partials(const double *__restrict__ part, int nblk, int bpad,
+                                               int col, double *red4 /* 256 doubles */) {
+  const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (col < bpad)
+    for (int b = s; b < nblk; b += 4) acc += part[(int64_t)b * bpad + col];
+  red4[s * 64 + c] = acc;
+  __syncthreads();
+  double tot = red4[c] + red4[64 + c] + red4[128 + c] + red4[192 + c];
+  __syncthreads();
+  return tot;
+}
+
+// After the probe-norm sweep: nu_0 = ||v||, first coefficients, activity flags.
+__global__ __launch_bounds__(256) void k_fin_init(StepState st, const double *__restrict__ partN,
+                                                  int nblk, int sphere, double n_as_double) {
+  __shared__ double red4[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double s = sum_partials(partN, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    const double nu0 = sqrt(s);
+    const int act = (col < st.nprobes) && (nu0 > 0.0);
+    st.nu[col] = nu0;
+    // sphere probes are sqrt(n) g/||g|| (src/primate/random.py:36-41): same direction, norm^2 = n
+    st.vnorm2[col] = sphere ? n_as_double : s;
+    st.active[col] = act;
+    st.steps[col] = 0;
+    st.coefA[col] = act ? 1.0 / nu0 : 0.0;
+    st.coefA[st.bpad + col] = 0.0;
+  }
+}
+
+// After sweep A of step j: alpha_j, and the sweep-B coefficient cB = alpha_j / nu_j.
+__global__ __launch_bounds__(256) void k_fin_alpha(StepState st, const double *__restrict__ partA,
+                                                   int nblk, int j) {
+  __shared__ double red4[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double a = sum_partials(partA, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    const int act = st.active[col];
+    if (act) st.alpha[(int64_t)j * st.bpad + col] = a;
+    st.coefB[col] = act ? a / st.nu[(int64_t)j * st.bpad + col] : 0.0;
+  }
+}
+
+// After the last sweep of step j: beta_{j+1} = ||w||, stop rule (lanczos.h:139-142), next sc/cp.
+__global__ __launch_bounds__(256) void k_fin_beta(StepState st, const double *__restrict__ partN,
+                                                  int nblk, int j, double residual_tol) {
+  __shared__ double red4[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double s = sum_partials(partN, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    double sc = 0.0, cp = 0.0;
+    if (st.active[col]) {
+      const double beta = sqrt(s);
+      st.nu[(int64_t)(j + 1) * st.bpad + col] = beta;
+      st.steps[col] = j + 1;
+      if (beta < residual_tol || (j + 1) == st.deg || !(beta == beta)) {
+        st.active[col] = 0;
+      } else {
+        sc = 1.0 / beta;
+        cp = beta / st.nu[(int64_t)j * st.bpad + col];
+      }
+    }
+    st.coefA[col] = sc;
+    st.coefA[st.bpad + col] = cp;
+  }
+}
+
+// After a sweep-B chunk: gamma_i = (W_t . w) / nu_t^2 unless |q_t . w| <= 2 eps sqrt(n)
+// (lanczos.h:53,62: the projection is skipped when it is below the orthogonality tolerance).
+__global__ __launch_bounds__(256) void k_fin_gamma(StepState st, const double *__restrict__ partD,
+                                                   int nblk, int j, int i0, double orth_tol) {
+  __shared__ double red4[256];
+  const int i = blockIdx.y;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double d = sum_partials(partD + (int64_t)i * nblk * st.bpad, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    const int t = j - i0 - i;
+    const double nu = st.nu[(int64_t)t * st.bpad + col];
+    double gm = 0.0;
+    if (st.active[col] && nu > 0.0) {
+      const double sproj = d / nu;
+      if (fabs(sproj) > orth_tol) gm = sproj / nu;
+    }
+    st.gamma[(int64_t)(i0 + i) * st.bpad + col] = gm;
+  }
+}
+
+// ---- probes ------------------------------------------------------------------------------------------
+// Column-major host-order staging chunk Xs (n x nc, ld = n, columns c0..c0+nc of the batch)
+// -> panel layout slot. 64x64 tiles through LDS so both sides are coalesced.
+template <typename F>
+__global__ __launch_bounds__(256) void k_cols_to_panel(int n, const F *__restrict__ Xs, int c0,
+                                                       int nc, F *W, int PW) {
+  __shared__ F tile[64][65];
+  const int r0 = blockIdx.x * 64, cb = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    const int col = cb + c, row = r0 + tx;
+    tile[c][tx] = (col < nc && row < n) ? Xs[(int64_t)col * n + row] : (F)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int row = r0 + r, col = cb + tx;
+    if (row < n && col < nc) {
+      const int gc = c0 + col;
+      W[((int64_t)(gc / PW) * n + row) * PW + (gc % PW)] = tile[tx][r];
+    }
+  }
+}
+
+// panel layout -> column-major chunk, optionally scaled per column (scale[gc], or 1 if null)
+template <typename F>
+__global__ __launch_bounds__(256) void k_panel_to_cols(int n, const F *__restrict__ W, int c0,
+                                                       int nc, F *Xs, int PW,
+                                                       const double *__restrict__ scale) {
+  __shared__ F tile[64][65];
+  const int r0 = blockIdx.x * 64, cb = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int row = r0 + r, col = cb + tx;
+    F x = (F)0;
+    if (row < n && col < nc) {
+      const int gc = c0 + col;
+      x = W[((int64_t)(gc / PW) * n + row) * PW + (gc % PW)];
+      if (scale) x = (F)((double)x * scale[gc]);
+    }
+    tile[r][tx] = x;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int col = cb + c, row = r0 + tx;
+    if (col < nc && row < n) Xs[(int64_t)col * n + row] = tile[tx][c];
+  }
+}
+
+template <typename F> __global__ void k_fill_zero(F *p, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = (F)0;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: the stream of probe id depends only on
+// (seed, id), never on the launch geometry or on how probes are sharded over GPUs.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Probe generation straight into the panel layout. A lane owns its V probe columns; one Philox
+// block serves 128 consecutive rows (Rademacher: 1 bit each) or 2 rows (normal: Box-Muller on two
+// 53-bit uniforms). Padding columns (id >= nprobes) are zero.
+//   Rademacher support is exactly {-1,+1} (reference: floor(2u)*2-1, src/primate/random.py:22-29).
+template <typename F, int LPR>
+__global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64_t seed,
+                                                    uint64_t probe_offset, int nprobes) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int rows_per_item = (pdf == 0) ? 128 : 2;
+  const int nitems = (n + rows_per_item - 1) / rows_per_item;
+  const int stride = gridDim.x * 4 * RPW;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int col0 = panel * PW + cl * V;
+  F *dst = W + ((int64_t)panel * n) * PW + cl * V;
+  VF mask;
+#pragma unroll
+  for (int v = 0; v < V; ++v) mask[v] = (col0 + v < nprobes) ? (F)1 : (F)0;
+  for (int it = (blockIdx.x * 4 + wave) * RPW + g; it < nitems; it += stride) {
+    uint32_t r[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const uint64_t id = probe_offset + (uint64_t)(col0 + v);
+      philox4x32_10((uint32_t)it, (uint32_t)(pdf != 0), (uint32_t)id, (uint32_t)(id >> 32), k0, k1,
+                    r[v]);
+    }
+    if (pdf == 0) {
+      const int rbase = it * 128;
+#pragma unroll 4
+      for (int b = 0; b < 128; ++b) {
+        const int row = rbase + b;
+        if (row < n) {
+          VF x;
+#pragma unroll
+          for (int v = 0; v < V; ++v) x[v] = ((r[v][b >> 5] >> (b & 31)) & 1u) ? (F)1 : (F)-1;
+          *(VF *)(dst + (int64_t)row * PW) = x * mask;
+        }
+      }
+    } else {
+      VF xa, xb;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const double u1 = ((double)(((uint64_t)r[v][0] << 21) ^ (r[v][1] >> 11)) + 0.5) *
+                          (1.0 / 9007199254740992.0);
+        const double u2 = ((double)(((uint64_t)r[v][2] << 21) ^ (r[v][3] >> 11)) + 0.5) *
+                          (1.0 / 9007199254740992.0);
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925 * u2, &sn, &cs);
+        xa[v] = (F)(rad * cs);
+        xb[v] = (F)(rad * sn);
+      }
+      const int row = it * 2;
+      if (row < n) *(VF *)(dst + (int64_t)row * PW) = xa * mask;
+      if (row + 1 < n) *(VF *)(dst + (int64_t)(row + 1) * PW) = xb * mask;
+    }
+  }
+}
+
+// ---- Gauss quadrature on the device -----------------------------------------------------------------
+__device__ __forceinline__ double apply_fun(int fun_id, double p0, double p1, double x) {
+  switch (fun_id) {
+    case 0: return x;
+    case 1: return fabs(x);
+    case 2: return sqrt(x);
+    case 3: return log(x > 2.220446049250313e-16 ? x : 2.220446049250313e-16);
+    case 4: return 1.0 / x;
+    case 5: return exp(p0 * x);
+    case 6: {
+      const double d = (p0 != p1) ? (p1 - p0) : 1.0;
+      double y = (x - p0) / d;
+      y = y < 0.0 ? 0.0 : (y > 1.0 ? 1.0 : y);
+      return 3.0 * y * y - 2.0 * y * y * y;
+    }
+    case 7: {
+      const double xx = (p1 != 0.0) ? fabs(x) : x;
+      return xx < p0 ? 0.0 : 1.0;
+    }
+    case 8: {
+      const int q = (int)p0;
+      const double xc = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);
+      double J = 1.0, pw = 1.0, s = 0.0;
+      for (int i = 0; i <= q; ++i) {
+        if (i > 0) {
+          J *= (2.0 * i - 1.0) / (2.0 * i);
+          pw *= (1.0 - xc * xc);
+        }
+        s += xc * pw * J;
+      }
+      return s;
+    }
+    default: return 0.0;
+  }
+}
+
+// One probe per lane; d, e, z live in LDS as [k][64] so a wave's accesses are conflict-free.
+// Implicit-shift QL (Wilkinson shift) carrying only the first row of the eigenvector matrix:
+// nodes = eigenvalues of T_k, weights = z^2 (Golub-Welsch; reference: integrate.py:61-64 via
+// LAPACK stemr, tridiag.py:10-11). Nodes are sorted ascending like LAPACK's output.
+// T_k is the full deg x deg Jacobi matrix with a zero tail after an early stop — what the
+// reference sees with freshly allocated alpha/beta (lanczos.py:101-102).
+__global__ __launch_bounds__(64) void k_quadrature(StepState st, int fun_id, double p0, double p1,
+                                                   double *__restrict__ quad,
+                                                   double *__restrict__ nodes,
+                                                   double *__restrict__ weights,
+                                                   int *__restrict__ fail) {
+  extern __shared__ double lds[];
+  const int k = st.deg;
+  const int lane = threadIdx.x;
+  const int col = blockIdx.x * 64 + lane;
+  double *d = lds + lane, *e = lds + k * 64 + lane, *z = lds + 2 * k * 64 + lane;
+#define D(i) d[(i) * 64]
+#define E(i) e[(i) * 64]
+#define Z(i) z[(i) * 64]
+  const bool live = col < st.nprobes;
+  for (int i = 0; i < k; ++i) {
+    D(i) = live ? st.alpha[(int64_t)i * st.bpad + col] : 0.0;
+    // E(i) couples i and i+1: beta_{i+1} = nu[i+1]
+    E(i) = (live && i + 1 < k) ? st.nu[(int64_t)(i + 1) * st.bpad + col] : 0.0;
+    Z(i) = (i == 0) ? 1.0 : 0.0;
+  }
+  int bad = 0;
+  if (live) {
+    for (int l = 0; l < k; ++l) {
+      int iter = 0;
+      for (;;) {
+        int m = l;
+        for (; m < k - 1; ++m) {
+          const double dd = fabs(D(m)) + fabs(D(m + 1));
+          if (fabs(E(m)) <= 2.220446049250313e-16 * dd) break;
+        }
+        if (m == l) break;
+        if (iter++ >= 60) {
+          bad = 1;
+          break;
+        }
+        double g = (D(l + 1) - D(l)) / (2.0 * E(l));
+        double r = hypot(g, 1.0);
+        g = D(m) - D(l) + E(l) / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i = m - 1;
+        bool underflow = false;
+        for (; i >= l; --i) {
+          double f = s * E(i);
+          const double b = c * E(i);
+          r = hypot(f, g);
+          E(i + 1) = r;
+          if (r == 0.0) {
+            D(i + 1) -= p;
+            E(m) = 0.0;
+            underflow = true;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = D(i + 1) - p;
+          r = (D(i) - g) * s + 2.0 * c * b;
+          p = s * r;
+          D(i + 1) = g + p;
+          g = c * r - b;
+          f = Z(i + 1);
+          Z(i + 1) = s * Z(i) + c * f;
+          Z(i) = c * Z(i) - s * f;
+        }
+        if (underflow) continue;
+        D(l) -= p;
+        E(l) = g;
+        E(m) = 0.0;
+      }
+    }
+    // insertion sort by node
+    for (int i = 1; i < k; ++i) {
+      const double dv = D(i), zv = Z(i);
+      int jj = i - 1;
+      for (; jj >= 0 && D(jj) > dv; --jj) {
+        D(jj + 1) = D(jj);
+        Z(jj + 1) = Z(jj);
+      }
+      D(jj + 1) = dv;
+      Z(jj + 1) = zv;
+    }
+    double s = 0.0;
+    for (int i = 0; i < k; ++i) {
+      const double th = D(i), tau = Z(i) * Z(i);
+      if (nodes) nodes[(int64_t)col * k + i] = th;
+      if (weights) weights[(int64_t)col * k + i] = tau;
+      if (fun_id >= 0) s += apply_fun(fun_id, p0, p1, th) * tau;
+    }
+    if (quad) {
+      const double vn2 = st.vnorm2[col];
+      // an all-zero probe is 0/0 in the reference (lanczos.h:120): surface it as NaN
+      quad[col] = (vn2 > 0.0) ? s * vn2 : __builtin_nan("");
+    }
+    if (bad) atomicOr(fail, 1);
+  }
+#undef D
+#undef E
+#undef Z
+}
+
+}  // namespace slq

@@ -1,0 +1,283 @@
+"""Object layer over the C-ABI: Context (one GPU + stream), DeviceOperator (operator plugin
+resident on that GPU) and LanczosPlan (workspace + state of one batched lock-step Lanczos run).
+
+Everything numeric happens in libslq's HIP kernels; this file only marshals arrays.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, ptr
+
+
+def fun_spec(fun, **kwargs) -> tuple:
+	"""Map a built-in spectral function name to (fun_id, params) following the defaults of the
+	reference registry (src/primate/special.py:78-107). Returns (None, None) for Python callables,
+	which are applied on the host to the returned nodes."""
+	if fun is None:
+		fun = "identity"
+	if not isinstance(fun, str):
+		return None, None
+	assert fun in _capi.FUN_IDS, "If given as a string, matrix_function be one of the builtin functions."
+	p = np.zeros(4)
+	if fun == "exp":
+		p[0] = kwargs.get("t", 1.0)
+	elif fun == "smoothstep":
+		p[0], p[1] = kwargs.get("a", 0.0), kwargs.get("b", 1.0)
+	elif fun == "numrank":
+		p[0], p[1] = kwargs.get("threshold", 0.000001), 1.0
+	elif fun == "step":
+		p[0], p[1] = kwargs.get("c", 0.0), float(kwargs.get("nonnegative", False))
+	elif fun == "softsign":
+		p[0] = kwargs.get("q", 10)
+	return _capi.FUN_IDS[fun], p
+
+
+class Context:
+	"""One per (process, GPU). `device=None` picks LOCAL_RANK (torchrun) or the current device."""
+
+	def __init__(self, device: Optional[int] = None, stream: Optional[int] = None):
+		L = _capi.lib()
+		if device is None:
+			device = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else -1
+		h = C.c_void_p()
+		check(L.slq_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+		self._h = h
+		self.device = device
+
+	def synchronize(self):
+		check(_capi.lib().slq_context_synchronize(self._h))
+
+	def meminfo(self) -> tuple:
+		f, t = C.c_size_t(), C.c_size_t()
+		check(_capi.lib().slq_context_meminfo(self._h, C.byref(f), C.byref(t)))
+		return f.value, t.value
+
+	def close(self):
+		if getattr(self, "_h", None):
+			_capi.lib().slq_context_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:  # noqa: BLE001
+			pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+	global _default_ctx
+	if _default_ctx is None:
+		_default_ctx = Context()
+	return _default_ctx
+
+
+class DeviceOperator:
+	"""Operator plugin resident on the GPU: the counterpart of the reference's C++ operator
+	wrappers (src/primate/include/eigen_operators.h:17-104, src/primate/include/pylinop.h:16-73).
+
+	Accepted inputs mirror the six overloads of the reference FFI
+	(src/primate/_lanczos.cpp:102-112): ndarray (dense), scipy.sparse (any format; stored as CSR
+	with int32 indices), or any object with `.matvec` and `.shape` (host-callback fallback).
+	"""
+
+	def __init__(self, A, dtype=None, ctx: Optional[Context] = None):
+		import scipy.sparse as sp
+
+		self.ctx = ctx or default_context()
+		L = _capi.lib()
+		if dtype is None:
+			dtype = getattr(A, "dtype", np.float64)
+		self.dtype = np.dtype(dtype)
+		dt = _capi.dtype_id(self.dtype)
+		assert hasattr(A, "shape") and len(A.shape) >= 2, "Operator must be at least two dimensional."
+		assert A.shape[0] == A.shape[1], "This function only works with square, symmetric matrices!"
+		self.shape = (int(A.shape[0]), int(A.shape[1]))
+		self._keep = []
+		h = C.c_void_p()
+		if isinstance(A, np.ndarray):
+			M = np.asfortranarray(A, dtype=self.dtype)
+			check(L.slq_dense_create(self.ctx._h, dt, M.shape[0], ptr(M), M.shape[0], C.byref(h)))
+			self.kind, self.nnz = "dense", M.size
+		elif sp.issparse(A):
+			M = sp.csr_matrix(A).astype(self.dtype)
+			M.sort_indices()
+			rowptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
+			colind = np.ascontiguousarray(M.indices, dtype=np.int32)
+			vals = np.ascontiguousarray(M.data, dtype=self.dtype)
+			check(L.slq_csr_create(self.ctx._h, dt, M.shape[0], M.nnz, ptr(rowptr), ptr(colind), ptr(vals), C.byref(h)))
+			self.kind, self.nnz = "csr", int(M.nnz)
+		else:
+			if not hasattr(A, "matvec"):
+				raise ValueError("Supplied object is missing 'matvec' attribute.")
+			n, np_dt = self.shape[0], self.dtype
+			self.error = None
+
+			def _cb(_user, x, y):
+				try:
+					ct = C.c_double if np_dt == np.float64 else C.c_float
+					xin = np.ctypeslib.as_array(C.cast(x, C.POINTER(ct)), shape=(n,))
+					out = np.asarray(A.matvec(xin.copy())).astype(np_dt, copy=False).ravel()
+					np.ctypeslib.as_array(C.cast(y, C.POINTER(ct)), shape=(n,))[:] = out[:n]
+					return 0
+				except Exception as e:  # noqa: BLE001
+					self.error = e
+					return 1
+
+			cb = _capi.MATVEC_FN(_cb)
+			self._keep.append(cb)
+			check(L.slq_callback_create(self.ctx._h, dt, n, cb, None, C.byref(h)))
+			self.kind, self.nnz = "callback", 0
+		self._h = h
+
+	def matmat(self, X: np.ndarray) -> np.ndarray:
+		X = np.asfortranarray(X.reshape(self.shape[1], -1), dtype=self.dtype)
+		Y = np.empty_like(X, order="F")
+		check(_capi.lib().slq_operator_matmat(self._h, ptr(X), X.shape[0], ptr(Y), Y.shape[0], X.shape[1]))
+		return Y
+
+	def close(self):
+		if getattr(self, "_h", None):
+			_capi.lib().slq_operator_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:  # noqa: BLE001
+			pass
+
+
+class LanczosPlan:
+	"""Workspace + state of one batched lock-step Lanczos run over `nprobes` probes."""
+
+	def __init__(self, op: DeviceOperator, nprobes: int, deg: int, orth: int = 0, keep_basis: bool = False):
+		self.op = op
+		n = op.shape[0]
+		self.nprobes = int(nprobes)
+		self.deg = min(int(deg), n)
+		self.orth = self.deg if orth < 0 or orth > self.deg else int(orth)
+		self.keep_basis = bool(keep_basis)
+		h = C.c_void_p()
+		check(_capi.lib().slq_plan_create(op.ctx._h, op._h, self.nprobes, int(deg), int(orth), int(keep_basis), C.byref(h)))
+		self._h = h
+
+	@property
+	def workspace_bytes(self) -> int:
+		b = C.c_size_t()
+		check(_capi.lib().slq_plan_workspace_bytes(self._h, C.byref(b)))
+		return b.value
+
+	def set_probes(self, X: np.ndarray):
+		X = np.asarray(X)
+		X = X.reshape(-1, 1) if X.ndim == 1 else X
+		assert X.shape == (self.op.shape[1], self.nprobes), f"probes must be {(self.op.shape[1], self.nprobes)}"
+		X = np.asfortranarray(X, dtype=self.op.dtype)
+		check(_capi.lib().slq_plan_set_probes(self._h, ptr(X), X.shape[0]))
+
+	def generate_probes(self, pdf: str = "rademacher", seed: int = 0, probe_offset: int = 0):
+		assert pdf in _capi.PDF_IDS, f"Invalid distribution '{pdf}' supplied."
+		check(_capi.lib().slq_plan_generate_probes(self._h, _capi.PDF_IDS[pdf], int(seed), int(probe_offset)))
+
+	def get_probes(self) -> np.ndarray:
+		X = np.empty((self.op.shape[0], self.nprobes), dtype=self.op.dtype, order="F")
+		check(_capi.lib().slq_plan_get_probes(self._h, ptr(X), X.shape[0]))
+		return X
+
+	def run(self, rtol: float = 1e-8):
+		rc = _capi.lib().slq_plan_run(self._h, float(rtol))
+		if rc == _capi.SLQ_ECALLBACK and getattr(self.op, "error", None) is not None:
+			raise self.op.error
+		check(rc)
+
+	def tridiag(self) -> tuple:
+		"""(alpha, beta, steps): alpha/beta are (nprobes, deg+1) with beta[:, 0] = 0."""
+		a = np.zeros((self.nprobes, self.deg + 1), dtype=self.op.dtype)
+		b = np.zeros((self.nprobes, self.deg + 1), dtype=self.op.dtype)
+		s = np.zeros(self.nprobes, dtype=np.int32)
+		check(_capi.lib().slq_plan_get_tridiag(self._h, ptr(a), ptr(b), ptr(s)))
+		return a, b, s
+
+	def quadrature(self, fun="identity", return_rule: bool = False, **fun_kwargs):
+		"""quad[i] = sum_k f(nodes[i,k]) weights[i,k] ||v_i||^2 ; optionally also (nodes, weights)."""
+		fid, params = fun_spec(fun, **fun_kwargs)
+		host_fun = fid is None
+		want_rule = return_rule or host_fun
+		quad = np.zeros(self.nprobes)
+		nodes = np.zeros((self.nprobes, self.deg)) if want_rule else None
+		weights = np.zeros((self.nprobes, self.deg)) if want_rule else None
+		check(
+			_capi.lib().slq_plan_quadrature(
+				self._h, 0 if host_fun else fid, ptr(params), ptr(quad), ptr(nodes), ptr(weights)
+			)
+		)
+		if host_fun:
+			## arbitrary Python callables run on the host over the P x k nodes (operators.py:150);
+			## the device returned sum(nodes*weights)*||v||^2, so ||v||^2 is recovered exactly
+			ident = np.sum(nodes * weights, axis=1)
+			vn2 = np.divide(quad, ident, out=np.zeros_like(quad), where=ident != 0)
+			self._vnorm2 = vn2
+			quad = np.array([np.sum(fun(nodes[i]) * weights[i]) for i in range(self.nprobes)]) * vn2
+		return (quad, nodes, weights) if return_rule else quad
+
+	def basis(self, probe: int = 0) -> np.ndarray:
+		Q = np.zeros((self.op.shape[0], self.deg), dtype=self.op.dtype, order="F")
+		check(_capi.lib().slq_plan_get_basis(self._h, int(probe), ptr(Q), Q.shape[0]))
+		return Q
+
+	def profile_enable(self, enable: bool = True):
+		check(_capi.lib().slq_plan_profile_enable(self._h, int(enable)))
+
+	def profile_read(self, reset: bool = True) -> dict:
+		pr = _capi.SlqProfile()
+		check(_capi.lib().slq_plan_profile_read(self._h, C.byref(pr), int(reset)))
+		return {k: {"ms": pr.ms[i], "launches": pr.launches[i]} for i, k in enumerate(_capi.KERNEL_CLASSES)}
+
+	def close(self):
+		if getattr(self, "_h", None):
+			_capi.lib().slq_plan_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:  # noqa: BLE001
+			pass
+
+
+def quad_batch(
+	op: DeviceOperator, X: Optional[np.ndarray], deg: int, orth: int = 0, fun="identity", rtol: float = 1e-8,
+	nprobes: Optional[int] = None, pdf: str = "rademacher", seed: int = 0, probe_offset: int = 0,
+	return_rule: bool = False, **fun_kwargs,
+):  # fmt: skip
+	"""One call for P probes (C-ABI slq_quad_batch): the batched form of the reference's per-probe
+	Python loop (src/primate/operators.py:145-150)."""
+	fid, params = fun_spec(fun, **fun_kwargs)
+	assert fid is not None, "quad_batch takes built-in function names; use LanczosPlan.quadrature for callables"
+	n = op.shape[0]
+	deg_eff = min(int(deg), n)
+	if X is not None:
+		X = np.asarray(X)
+		X = X.reshape(-1, 1) if X.ndim == 1 else X
+		X = np.asfortranarray(X, dtype=op.dtype)
+		nprobes = X.shape[1]
+	quad = np.zeros(nprobes)
+	nodes = np.zeros((nprobes, deg_eff)) if return_rule else None
+	weights = np.zeros((nprobes, deg_eff)) if return_rule else None
+	rc = _capi.lib().slq_quad_batch(
+		op.ctx._h, op._h, ptr(X), n, _capi.PDF_IDS[pdf], int(seed), int(probe_offset), int(nprobes), int(deg),
+		float(rtol), int(orth), fid, ptr(params), ptr(quad), ptr(nodes), ptr(weights),
+	)  # fmt: skip
+	if rc == _capi.SLQ_ECALLBACK and getattr(op, "error", None) is not None:
+		raise op.error
+	check(rc)
+	return (quad, nodes, weights) if return_rule else quad
