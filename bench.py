@@ -1,0 +1,262 @@
+"""bench.py — BASELINE.json's metric on BASELINE.json's config, on N GPUs of one node.
+
+Metric: probe-matvecs/s (1 probe-matvec = one Lanczos step for one probe: SpMV + three-term
+update + reorthogonalisation sweep + norm) on configs[1]: logdet by SLQ of the
+2D 5-point Laplacian, n = 1,000,000, nnz = 4,996,000, k = 30, 256 Rademacher probes per GPU,
+fp64. A "step" is one full pass of the hot path over one probe batch: draw 256 probes on the
+device, 30 lock-step Lanczos steps, on-device Gauss quadrature, sum f(theta)*tau*||v||^2, and
+(N > 1) one RCCL all-reduce of the three sufficient statistics of the trace estimator. The CSR
+operator is resident in HBM before the timed region. Probes shard across GPUs with no data-path
+collective (weak scaling: 256 probes per GPU; probe ids are global, so results do not depend on N).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--orth R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def laplacian_2d(m: int, dtype=np.float64):
+	import scipy.sparse as sp
+
+	T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
+	A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsr().astype(dtype)
+	A.sort_indices()
+	return A
+
+
+def laplacian_3d(m: int, dtype=np.float64):
+	import scipy.sparse as sp
+
+	T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(m, m))
+	I = sp.identity(m)
+	A = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T)).tocsr().astype(dtype)
+	A.sort_indices()
+	return A
+
+
+## ---- algorithmic-byte model -------------------------------------
+def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
+	"""B(j) = [(s+4) nnz + 4(n+1)]/b + (8 + 2 r_j) s n, r_j = min(j+1, orth)."""
+	r = 0 if orth == 0 else min(j + 1, orth)
+	return ((s + 4) * nnz + 4 * (n + 1)) / b + (8 + 2 * r) * s * n
+
+
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16):
+	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each vector panel is
+	read or written once per sweep, the CSR arrays once per panel of `pw` probes."""
+	npan = math.ceil(b / pw)
+	vec = s * n * b
+	csr = npan * ((s + 4) * nnz + 4 * (n + 1))
+	out = {"spmm_3term": 0.0, "axpy_norm": 0.0, "reorth_dot": 0.0, "reorth_update": 0.0}
+	launches = dict.fromkeys(out, 0)
+	out["axpy_norm"] += vec  # ||v||^2 of the probes
+	launches["axpy_norm"] += 1
+	for j in range(deg):
+		out["spmm_3term"] += csr + (2 if j == 0 else 3) * vec  # gather q_c, read q_p, write w
+		launches["spmm_3term"] += 1
+		r = 0 if orth == 0 else min(j + 1, orth)
+		if r == 0:
+			out["axpy_norm"] += 3 * vec  # read w, q_c; write w
+			launches["axpy_norm"] += 1
+		else:
+			for i0 in range(0, r, chunk):
+				rc = min(chunk, r - i0)
+				out["reorth_dot"] += (rc + (2 if i0 == 0 else 1)) * vec
+				launches["reorth_dot"] += 1
+			out["reorth_update"] += (r + 2) * vec
+			launches["reorth_update"] += 1
+	return out, launches
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=10)
+	ap.add_argument("--warmup", type=int, default=2)
+	ap.add_argument("--orth", type=int, default=3, help="reorthogonalisation depth (MatrixFunction default: 3)")
+	ap.add_argument("--deg", type=int, default=30)
+	ap.add_argument("--probes", type=int, default=256, help="probes per GPU")
+	ap.add_argument("--workload", default="lap2d_1000", help="lap2d_<m> | lap3d_<m>")
+	ap.add_argument("--fun", default="log")
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--cpu-seconds", type=float, default=15.0)
+	args = ap.parse_args()
+
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	N = args.gpus
+	assert world == N or (N == 1 and world == 1), f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+	import torch
+
+	dist = None
+	if world > 1:
+		import torch.distributed as dist
+
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		torch.cuda.set_device(local_rank)
+		dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+	else:
+		torch.cuda.set_device(local_rank)
+
+	from primate_amd.engine import Context, DeviceOperator, LanczosPlan
+
+	kind, m = args.workload.split("_")
+	A = laplacian_2d(int(m)) if kind == "lap2d" else laplacian_3d(int(m))
+	n, nnz, s = A.shape[0], A.nnz, 8
+	ctx = Context(device=local_rank)
+	op = DeviceOperator(A, ctx=ctx)  # CSR resident in HBM before the timed region
+	P, deg = args.probes, min(args.deg, n)
+	orth = deg if args.orth < 0 or args.orth > deg else args.orth
+	plan = LanczosPlan(op, P, deg, orth)
+	stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+
+	def step(it: int):
+		## probe ids are global: rank r draws ids [ (it*world + r) * P, ... + P )
+		plan.generate_probes("rademacher", seed=1234, probe_offset=(it * world + rank) * P)
+		plan.run(1e-8)
+		q = plan.quadrature(args.fun)  # device QL + reduction; returns P doubles (synchronises)
+		if dist is not None:
+			st = torch.tensor([q.sum(), (q * q).sum(), float(len(q))], dtype=torch.float64, device="cuda")
+			dist.all_reduce(st)  # RCCL over xGMI: the only collective on the path
+			return st
+		return q
+
+	def barrier():
+		if dist is not None:
+			dist.barrier()
+		torch.cuda.synchronize()
+		ctx.synchronize()
+
+	for it in range(args.warmup):
+		step(it)
+	plan.profile_enable(True)
+	plan.profile_read(reset=True)
+	barrier()
+	t0 = time.perf_counter()
+	ests = []
+	for it in range(args.steps):
+		out = step(args.warmup + it)
+		ests.append(out)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if dist is not None:
+		tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+		elapsed = float(tmax.item())
+	prof = plan.profile_read(reset=True)
+	plan.profile_enable(False)
+
+	if dist is not None:
+		tot = torch.stack(ests).sum(0).cpu().numpy()
+		estimate = tot[0] / tot[2]
+	else:
+		estimate = float(np.mean(np.concatenate(ests)))
+
+	probe_matvecs = world * P * deg * args.steps
+	value = probe_matvecs / elapsed
+	ms_per_step = elapsed / args.steps * 1e3
+
+	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
+	pw = 128 if P > 64 else (64 if P > 32 else (32 if P > 16 else 16))
+	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth)
+	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
+	dom = max(cand, key=cand.get)
+	launches = prof[dom]["launches"]
+	avg_ms = prof[dom]["ms"] / launches
+	alg_bytes_per_launch = kb[dom] / kl[dom]
+	achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+	traffic = None
+	pmc = ROOT / "profiles" / "pmc_summary.json"
+	if pmc.exists():
+		try:
+			rec = json.loads(pmc.read_text())
+			key = f"{args.workload}/P{P}/k{deg}/orth{orth}"
+			traffic = rec.get(key, {}).get(dom, {}).get("hbm_bytes_per_launch")
+		except Exception:  # noqa: BLE001
+			traffic = None
+	roofline = {
+		"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+		"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+		"alg_bytes_per_launch": int(alg_bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
+	}  # fmt: skip
+	## whole-loop view: SURVEY §8(d) contract bytes per probe-matvec / wall time of the step
+	contract = sum(contract_bytes_per_probe_matvec(n, nnz, s, P, j, orth) for j in range(deg)) / deg
+	kernels = {
+		k: {
+			"ms_per_step": round(prof[k]["ms"] / args.steps, 3),
+			"launches_per_step": prof[k]["launches"] / args.steps,
+			**({"alg_GBps": round(kb[k] * args.steps / (prof[k]["ms"] * 1e-3) / 1e9, 1)} if k in kb and prof[k]["ms"] > 0 else {}),
+		}
+		for k in prof
+		if prof[k]["launches"] > 0
+	}
+
+	line = {
+		"metric": "probe-matvecs/sec", "value": round(value, 1), "unit": "probe-matvecs/s", "n_gpus": world,
+		"steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+		"scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+		"config": {
+			"workload": f"configs[1]: logdet via SLQ, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={args.fun}",
+			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
+			"parallelism": f"probe-sharded x{world}, operator replicated",
+		},
+		"trace_estimates_per_s": round(world * P * args.steps / elapsed, 1),
+		"estimate": float(estimate),
+		"roofline": roofline,
+		"loop": {
+			"contract_bytes_per_probe_matvec": int(contract),
+			"contract_GBps_per_gpu": round(value / world * contract / 1e9, 1),
+			"contract_frac_of_peak": round(value / world * contract / 1e9 / HBM_PEAK_GBS, 4),
+		},
+		"kernels": kernels,
+	}  # fmt: skip
+
+	## ---- CPU baseline: the oracle (C restatement of the reference kernel), rank 0, N = 1 only ---
+	if rank == 0 and world == 1 and not args.no_cpu_baseline:
+		from oracle import oracle
+
+		rng = np.random.default_rng(1234)
+		mk = lambda c: np.asfortranarray(np.floor(rng.random((n, c)) * 2) * 2 - 1)  # noqa: E731
+		t = time.perf_counter()
+		oracle.quad_batch(A, mk(1), deg, orth, fun=args.fun, fresh_q=False, nthreads=1)
+		one = time.perf_counter() - t
+		cnt = int(max(2, min(32, args.cpu_seconds / max(one, 1e-3))))
+		X = mk(cnt)
+		t = time.perf_counter()
+		qc = oracle.quad_batch(A, X, deg, orth, fun=args.fun, fresh_q=False, nthreads=1)
+		tc = time.perf_counter() - t
+		line["cpu_baseline"] = {
+			"value": round(cnt * deg / tc, 2), "unit": "probe-matvecs/s", "cores": 1, "kind": "port",
+			"sample": f"{cnt} Rademacher probes x k={deg}, orth={orth}, same operator, 1 thread (the reference's execution model; "
+			f"oracle/slq_oracle.c restating lanczos.h:43-149 + CSC SpMV + QL quadrature), {tc:.1f} s",
+			"s_per_probe": round(tc / cnt, 3), "estimate": float(np.mean(qc)),
+		}  # fmt: skip
+
+	if rank == 0:
+		print(json.dumps(line))
+	if dist is not None:
+		dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()

@@ -154,6 +154,14 @@ int slq_plan_get_basis(slq_plan *plan, int probe, void *Q, int64_t ldq);
 int slq_plan_fun_action(slq_plan *plan, int fun_id, const double *fun_params, void *Y,
                         int64_t ldy);
 
+/* Stand-alone Gauss quadrature of nb Jacobi matrices on the device (the C-ABI form of
+ * integrate.quadrature(d, e, deg, quad="gw"), src/primate/integrate.py:57-64): d, e are
+ * nb x deg row-major doubles, e[:,0] is ignored (must be 0 in the reference, integrate.py:59) and
+ * e[:,i] couples i-1 and i. quad[i] = sum_k f(nodes[i,k]) weights[i,k]. Any output may be NULL. */
+int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e,
+                         int fun_id, const double *fun_params, double *quad, double *nodes,
+                         double *weights);
+
 /* Per-kernel device time accumulated by HIP events on the context stream (for bench.py's
  * roofline line). enable != 0 turns event recording on for subsequent slq_plan_run calls. */
 enum {

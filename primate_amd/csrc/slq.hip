@@ -496,7 +496,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->bpad = p->NP * p->PW;
   p->S = ring_slots(deg, orth, p->keep_basis);
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
-  p->rmax = std::max(orth, 1);
+  p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   grid_sizes(p->n, p->LPR, ctx->num_cus, &p->nblkA, &p->nblkS);
   memset(&p->acc, 0, sizeof(p->acc));
   memset(&p->st, 0, sizeof(p->st));
@@ -684,6 +684,8 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
   return SLQ_OK;
 }
 
+static int launch_reorth_update(slq_plan *p, int j, int r);
+
 extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!p) return fail(SLQ_EINVAL, "plan is NULL");
   if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
@@ -741,25 +743,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(256), 0, st, p->st,
                                     p->part, p->nblkS, j, i0, orth_tol));
       }
-      const int V = p->dtype == SLQ_F64 ? 2 : 4;
-      // gamma for up to kUpdChunk columns is staged in LDS per launch (<= 160 KiB per workgroup)
-      const int kUpdChunk = (int)((150 * 1024 - sizeof(double) * kWaves * 64 * V) / ((size_t)p->PW * p->esz));
-      for (int i0 = 0; i0 < r; i0 += kUpdChunk) {
-        const int rc = std::min(kUpdChunk, r - i0);
-        const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
-        if (lds > 48 * 1024) {
-          hipError_t ae = hipSuccess;
-          DISPATCH(p->dtype, p->LPR,
-                   ae = hipFuncSetAttribute((const void *)k_reorth_update<F, L>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          HIP_TRY(ae);
-        }
-        PROFILED(p, SLQ_K_REORTH_UPD,
-                 DISPATCH(p->dtype, p->LPR,
-                          (k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(
-                              p->n, (F *)p->ring, p->slot_stride, S, j, i0, rc,
-                              p->st.gamma + (size_t)i0 * bp, p->part, bp))));
-      }
+      SLQ_TRY(launch_reorth_update(p, j, r));
     }
     PROFILED(p, SLQ_K_FINALIZE,
              hipLaunchKernelGGL(k_fin_beta, gF, dim3(256), 0, st, p->st, p->part, p->nblkS, j, residual_tol));
@@ -855,10 +839,124 @@ extern "C" int slq_plan_get_basis(slq_plan *p, int probe, void *Q, int64_t ldq) 
   return rc;
 }
 
+static int update_chunk_cols(const slq_plan *p) {
+  const int V = p->dtype == SLQ_F64 ? 2 : 4;
+  return (int)((150 * 1024 - sizeof(double) * kWaves * 64 * V) / ((size_t)p->PW * p->esz));
+}
+
+// w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
+static int launch_reorth_update(slq_plan *p, int j, int r) {
+  hipStream_t st = p->ctx->stream;
+  const int V = p->dtype == SLQ_F64 ? 2 : 4;
+  const int kUpdChunk = update_chunk_cols(p);
+  const dim3 gS(p->nblkS, p->NP);
+  for (int i0 = 0; i0 < r; i0 += kUpdChunk) {
+    const int rc = std::min(kUpdChunk, r - i0);
+    const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
+    if (lds > 48 * 1024) {
+      hipError_t ae = hipSuccess;
+      DISPATCH(p->dtype, p->LPR,
+               ae = hipFuncSetAttribute((const void *)k_reorth_update<F, L>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(ae);
+    }
+    PROFILED(p, SLQ_K_REORTH_UPD,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(
+                          p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
+                          p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad))));
+  }
+  return SLQ_OK;
+}
+
 extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_params, void *Y, int64_t ldy) {
-  (void)fun_id; (void)fun_params; (void)Y; (void)ldy;
-  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
-  return fail(SLQ_EINVAL, "slq_plan_fun_action: the f(A)v action (SURVEY.md §8 row f1) is not implemented yet");
+  if (!p || !Y) return fail(SLQ_EINVAL, "plan/Y is NULL");
+  if (!p->keep_basis) return fail(SLQ_EINVAL, "plan was created without keep_basis");
+  if (!p->ran) return fail(SLQ_EINVAL, "slq_plan_fun_action: no completed run");
+  if (fun_id < SLQ_FUN_IDENTITY || fun_id > SLQ_FUN_SOFTSIGN) return fail(SLQ_EINVAL, "Unknown function id %d.", fun_id);
+  if (ldy < p->n) return fail(SLQ_EINVAL, "ldy < n");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const int deg = p->deg;
+  const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
+  const size_t lds = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8;
+  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip eigenvector solve", deg);
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fun_coeffs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipMemsetAsync(p->fail_d, 0, sizeof(int), st));
+  // gamma[t] = -g_t so that the update kernel's "w -= gamma W" accumulates +g_t W_t into a zeroed slot
+  PROFILED(p, SLQ_K_QUADRATURE,
+           (k_fun_coeffs<<<dim3(p->nprobes), dim3(64), lds, st>>>(p->st, fun_id, p0, p1, -1.0, 1, p->st.gamma, p->fail_d)));
+  // padding columns keep stale gamma: zero them (their W columns are zero anyway, but stay NaN-free)
+  if (p->bpad > p->nprobes)
+    for (int t = 0; t < deg; ++t)
+      HIP_TRY(hipMemsetAsync(p->st.gamma + (size_t)t * p->bpad + p->nprobes, 0, (size_t)(p->bpad - p->nprobes) * 8, st));
+  // output accumulates in slot `deg` (the spare slot behind the basis; it held the last residual)
+  HIP_TRY(hipMemsetAsync(slot_ptr(p, deg), 0, (size_t)p->slot_stride * p->esz, st));
+  // the update kernel walks t = (deg-1) - i for i = 0..deg-1: k_fun_coeffs stored g_t in row deg-1-t
+  SLQ_TRY(launch_reorth_update(p, deg - 1, deg));
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
+  SLQ_TRY(panel_to_host(p, deg, 0, p->nprobes, Y, ldy, nullptr));
+  if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
+  return SLQ_OK;
+}
+
+extern "C" int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e,
+                                    int fun_id, const double *fun_params, double *quad, double *nodes,
+                                    double *weights) {
+  if (!ctx || !d || !e) return fail(SLQ_EINVAL, "ctx/d/e is NULL");
+  if (nb <= 0 || deg <= 0 || deg > kMaxDeg) return fail(SLQ_EINVAL, "bad batch size or degree");
+  if (fun_id < SLQ_FUN_NONE || fun_id > SLQ_FUN_SOFTSIGN) return fail(SLQ_EINVAL, "Unknown function id %d.", fun_id);
+  const size_t lds = (size_t)3 * deg * 64 * 8;
+  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip tridiagonal solver", deg);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int bp = (nb + 63) / 64 * 64;
+  StepState s;
+  memset(&s, 0, sizeof(s));
+  s.bpad = bp;
+  s.nprobes = nb;
+  s.deg = deg;
+  double *buf = nullptr;
+  const size_t in = (size_t)nb * deg;
+  const size_t total = (size_t)(2 * (deg + 1) + 1) * bp + 2 * in + bp + 2 * (size_t)bp * deg + 8;
+  HIP_TRY(hipMalloc((void **)&buf, total * 8));
+  double *q = buf;
+  s.alpha = q; q += (size_t)(deg + 1) * bp;
+  s.nu = q; q += (size_t)(deg + 1) * bp;
+  s.vnorm2 = q; q += bp;
+  double *dd = q; q += in;
+  double *de = q; q += in;
+  double *dq = q; q += bp;
+  double *dn = q; q += (size_t)bp * deg;
+  double *dw = q; q += (size_t)bp * deg;
+  int *dfail = (int *)q;
+  int rc = SLQ_OK;
+  hipError_t err = hipMemcpyAsync(dd, d, in * 8, hipMemcpyHostToDevice, st);
+  if (err == hipSuccess) err = hipMemcpyAsync(de, e, in * 8, hipMemcpyHostToDevice, st);
+  if (err == hipSuccess) err = hipMemsetAsync(dfail, 0, sizeof(int), st);
+  if (err == hipSuccess) {
+    k_load_tridiag<<<dim3((bp + 255) / 256), dim3(256), 0, st>>>(s, dd, de, nb);
+    if (lds > 48 * 1024)
+      err = hipFuncSetAttribute((const void *)k_quadrature, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (err == hipSuccess) {
+    const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
+    k_quadrature<<<dim3((nb + 63) / 64), dim3(64), lds, st>>>(s, fun_id, p0, p1, dq, dn, dw, dfail);
+    err = hipGetLastError();
+  }
+  int bad = 0;
+  if (err == hipSuccess) err = hipMemcpyAsync(&bad, dfail, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess && quad) err = hipMemcpyAsync(quad, dq, (size_t)nb * 8, hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess && nodes) err = hipMemcpyAsync(nodes, dn, in * 8, hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess && weights) err = hipMemcpyAsync(weights, dw, in * 8, hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipStreamSynchronize(st);
+  hipFree(buf);
+  if (err != hipSuccess) rc = fail(SLQ_EHIP, "slq_quadrature_batch: %s", hipGetErrorString(err));
+  else if (bad) rc = fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one rule");
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -776,4 +776,108 @@ __global__ __launch_bounds__(64) void k_quadrature(StepState st, int fun_id, dou
 #undef Z
 }
 
+
+// ---- f(A)v coefficients: one wave per probe, full eigenvector matrix in LDS -----------------------
+// f(A) x ~= ||x|| Q Y (f(theta) * Y[0,:])   (reference: MatrixFunction._matvec,
+// src/primate/operators.py:118-124). With unnormalised ring vectors W_t = nu_t q_t this is
+// sum_t g_t W_t with g_t = ||x|| c_t / nu_t, c = Y (f(theta) * Y[0,:]).
+// All 64 lanes run the scalar QL recurrences redundantly (identical values, so the LDS writes to
+// d/e are the same from every lane); the plane rotations are applied lane-parallel, lane r owning
+// rows r, r+64, ... of Y. coef[t][col] = sign * g_t (0 where nu_t = 0, i.e. past an early stop);
+// reverse_rows stores g_t in row k-1-t, the order in which k_reorth_update walks the ring.
+__global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, double p0, double p1,
+                                                   double sign, int reverse_rows,
+                                                   double *__restrict__ coef,
+                                                   int *__restrict__ fail) {
+  extern __shared__ double lds[];
+  const int k = st.deg, ldz = k + 1;
+  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
+  const int lane = threadIdx.x, col = blockIdx.x;
+  for (int i = lane; i < k; i += 64) {
+    d[i] = st.alpha[(int64_t)i * st.bpad + col];
+    e[i] = (i + 1 < k) ? st.nu[(int64_t)(i + 1) * st.bpad + col] : 0.0;
+  }
+  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
+  __syncthreads();
+  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
+  __syncthreads();
+  int bad = 0;
+  for (int l = 0; l < k; ++l) {
+    int iter = 0;
+    for (;;) {
+      int m = l;
+      for (; m < k - 1; ++m) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m == l) break;
+      if (iter++ >= 60) {
+        bad = 1;
+        break;
+      }
+      double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+      double r = hypot(g, 1.0);
+      g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+      double s = 1.0, c = 1.0, p = 0.0;
+      int i = m - 1;
+      bool underflow = false;
+      for (; i >= l; --i) {
+        double f = s * e[i];
+        const double b = c * e[i];
+        r = hypot(f, g);
+        e[i + 1] = r;
+        if (r == 0.0) {
+          d[i + 1] -= p;
+          e[m] = 0.0;
+          underflow = true;
+          break;
+        }
+        s = f / r;
+        c = g / r;
+        g = d[i + 1] - p;
+        r = (d[i] - g) * s + 2.0 * c * b;
+        p = s * r;
+        d[i + 1] = g + p;
+        g = c * r - b;
+        for (int row = lane; row < k; row += 64) {
+          const double z1 = Z[row * ldz + i + 1], z0 = Z[row * ldz + i];
+          Z[row * ldz + i + 1] = s * z0 + c * z1;
+          Z[row * ldz + i] = c * z0 - s * z1;
+        }
+      }
+      if (underflow) continue;
+      d[l] -= p;
+      e[l] = g;
+      e[m] = 0.0;
+    }
+  }
+  __syncthreads();
+  // e[i] <- f(theta_i) * Y[0,i]
+  for (int i = lane; i < k; i += 64) e[i] = apply_fun(fun_id, p0, p1, d[i]) * Z[i];
+  __syncthreads();
+  const double xnorm = sqrt(st.vnorm2[col]);
+  for (int t = lane; t < k; t += 64) {
+    double c = 0.0;
+    for (int i = 0; i < k; ++i) c += Z[t * ldz + i] * e[i];
+    const double nu = st.nu[(int64_t)t * st.bpad + col];
+    const int row = reverse_rows ? (k - 1 - t) : t;
+    coef[(int64_t)row * st.bpad + col] = (nu > 0.0) ? sign * xnorm * c / nu : 0.0;
+  }
+  if (bad && lane == 0) atomicOr(fail, 1);
+}
+
+// transpose host-order (nb x deg row-major) tridiagonal coefficients into the [deg+1][bpad] device
+// layout of StepState (stand-alone quadrature entry)
+__global__ void k_load_tridiag(StepState st, const double *__restrict__ d, const double *__restrict__ e,
+                               int nb) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= st.bpad) return;
+  for (int i = 0; i < st.deg; ++i) {
+    st.alpha[(int64_t)i * st.bpad + col] = (col < nb) ? d[(int64_t)col * st.deg + i] : 0.0;
+    st.nu[(int64_t)i * st.bpad + col] = (col < nb && i > 0) ? e[(int64_t)col * st.deg + i] : 0.0;
+  }
+  st.nu[(int64_t)st.deg * st.bpad + col] = 0.0;
+  st.vnorm2[col] = 1.0;
+}
+
 }  // namespace slq

@@ -1,0 +1,102 @@
+"""Multi-GPU sharding of the probe set: one process per GPU, operator replicated, probes split, no
+data-path collective; ONE reduction at the end.
+
+Backend-agnostic on purpose: `torch.distributed` with backend "nccl" is RCCL over xGMI on the
+MI355X node; the same code runs under "gloo" in the CPU tests.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .estimators import Covariance
+
+
+def shard_range(nprobes: int, rank: int, world: int) -> tuple:
+	"""Contiguous block [lo, hi) of global probe ids owned by `rank` (first ranks take the remainder)."""
+	base, rem = divmod(int(nprobes), int(world))
+	lo = rank * base + min(rank, rem)
+	return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_statistics(samples: np.ndarray) -> np.ndarray:
+	"""(count, mean, M2) of the local per-probe values: the sufficient statistics of the trace
+	estimator (src/primate/stats.py:47-49,77-86)."""
+	x = np.asarray(samples, dtype=np.float64).ravel()
+	if x.size == 0:
+		return np.zeros(3)
+	mu = x.mean()
+	return np.array([x.size, mu, np.sum((x - mu) ** 2)])
+
+
+def merge_statistics(stats: np.ndarray) -> tuple:
+	"""Fold per-rank (count, mean, M2) rows in rank order with the batch-Welford formula of
+	`Covariance.update` (stats.py:77-86). Returns (count, mean, sample variance)."""
+	acc = Covariance(dim=1)
+	for n, mu, m2 in np.asarray(stats, dtype=np.float64).reshape(-1, 3):
+		acc.merge(int(n), np.array([mu]), np.array([[m2]]))
+	var = acc.S.item() / (acc.n - 1) if acc.n > 1 else float("inf")
+	return acc.n, acc.mu.item(), var
+
+
+def allreduce_trace(samples: np.ndarray, group=None, device: Optional[str] = None, gather_samples: bool = False):
+	"""The single collective of a sharded hutch(): all-gather each rank's (count, mean, M2) — 3 doubles
+	per rank — and merge in rank order, so every rank ends with the same, order-deterministic result.
+	With gather_samples=True the per-probe values themselves are gathered (<= a few thousand doubles)
+	so the host can replay `MeanEstimator.update` in the reference's exact order (bit-identical to a
+	1-GPU run)."""
+	import torch
+	import torch.distributed as dist
+
+	world = dist.get_world_size(group)
+	dev = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+	if gather_samples:
+		x = torch.as_tensor(np.asarray(samples, dtype=np.float64).ravel(), device=dev)
+		sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+		dist.all_gather(sizes, torch.tensor([x.numel()], dtype=torch.int64, device=dev), group=group)
+		mx = int(max(int(s.item()) for s in sizes))
+		pad = torch.zeros(mx, dtype=torch.float64, device=dev)
+		pad[: x.numel()] = x
+		bufs = [torch.zeros(mx, dtype=torch.float64, device=dev) for _ in range(world)]
+		dist.all_gather(bufs, pad, group=group)
+		allx = np.concatenate([b[: int(s.item())].cpu().numpy() for b, s in zip(bufs, sizes)])
+		n, mu, var = merge_statistics(local_statistics(allx))
+		return n, mu, var, allx
+	st = torch.as_tensor(local_statistics(samples), device=dev)
+	bufs = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+	dist.all_gather(bufs, st, group=group)
+	return merge_statistics(np.stack([b.cpu().numpy() for b in bufs]))
+
+
+def allreduce_sum(x: np.ndarray, group=None, device: Optional[str] = None) -> np.ndarray:
+	"""Sum an n-vector over ranks (the diag estimator's numer/denom)."""
+	import torch
+	import torch.distributed as dist
+
+	dev = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+	t = torch.as_tensor(np.ascontiguousarray(x), device=dev)
+	dist.all_reduce(t, group=group)
+	return t.cpu().numpy()
+
+
+def sharded_hutch_device(op, nprobes: int, deg: int, orth: int, fun="identity", pdf: str = "rademacher", seed: int = 0, rtol: float = 1e-8, group=None, **fun_kwargs):
+	"""hutch() with a fixed probe budget, probes drawn on the device and sharded over the ranks of
+	`group`. Global probe ids make the per-probe values independent of the number of GPUs."""
+	import torch.distributed as dist
+
+	from .engine import LanczosPlan
+
+	rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+	lo, hi = shard_range(nprobes, rank, world)
+	q = np.zeros(0)
+	if hi > lo:
+		plan = LanczosPlan(op, hi - lo, deg, orth)
+		plan.generate_probes(pdf, seed=seed, probe_offset=lo)
+		plan.run(rtol)
+		q = plan.quadrature(fun, **fun_kwargs)
+		plan.close()
+	if world == 1:
+		return merge_statistics(local_statistics(q))
+	return allreduce_trace(q, group=group)

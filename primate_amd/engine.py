@@ -229,6 +229,14 @@ class LanczosPlan:
 			quad = np.array([np.sum(fun(nodes[i]) * weights[i]) for i in range(self.nprobes)]) * vn2
 		return (quad, nodes, weights) if return_rule else quad
 
+	def fun_action(self, fun="identity", **fun_kwargs) -> np.ndarray:
+		"""Y[:, i] = f(A) x_i from the retained basis (needs keep_basis); built-in `fun` names only."""
+		fid, params = fun_spec(fun, **fun_kwargs)
+		assert fid is not None, "fun_action evaluates built-in function names on the device"
+		Y = np.zeros((self.op.shape[0], self.nprobes), dtype=self.op.dtype, order="F")
+		check(_capi.lib().slq_plan_fun_action(self._h, fid, ptr(params), ptr(Y), Y.shape[0]))
+		return Y
+
 	def basis(self, probe: int = 0) -> np.ndarray:
 		Q = np.zeros((self.op.shape[0], self.deg), dtype=self.op.dtype, order="F")
 		check(_capi.lib().slq_plan_get_basis(self._h, int(probe), ptr(Q), Q.shape[0]))
@@ -281,3 +289,18 @@ def quad_batch(
 		raise op.error
 	check(rc)
 	return (quad, nodes, weights) if return_rule else quad
+
+
+def quadrature_batch(d: np.ndarray, e: np.ndarray, fun=None, ctx: Optional[Context] = None, **fun_kwargs):
+	"""Gauss quadrature rules of a batch of Jacobi matrices on the device (slq_quadrature_batch).
+	d, e: (nb, deg) with e[:, 0] ignored. Returns (nodes, weights) or, with `fun`, (quad, nodes, weights)."""
+	ctx = ctx or default_context()
+	d = np.ascontiguousarray(np.atleast_2d(d), dtype=np.float64)
+	e = np.ascontiguousarray(np.atleast_2d(e), dtype=np.float64)
+	assert d.shape == e.shape
+	nb, deg = d.shape
+	nodes, weights = np.zeros((nb, deg)), np.zeros((nb, deg))
+	fid, params = (_capi.FUN_NONE, np.zeros(4)) if fun is None else fun_spec(fun, **fun_kwargs)
+	quad = np.zeros(nb)
+	check(_capi.lib().slq_quadrature_batch(ctx._h, nb, deg, ptr(d), ptr(e), fid, ptr(params), ptr(quad), ptr(nodes), ptr(weights)))
+	return (nodes, weights) if fun is None else (quad, nodes, weights)

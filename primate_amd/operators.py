@@ -1,0 +1,148 @@
+"""`MatrixFunction`: the SLQ operator x -> f(A) x / x^T f(A) x with the reference's interface
+(src/primate/operators.py:36-161), evaluated by libslq on the MI355X.
+
+What changes under the hood:
+  * `.quad(X)` advances ALL columns of X in lock-step in one device run (the reference loops over
+    columns in Python and crosses its FFI once per probe, operators.py:145-150);
+  * the operator is uploaded once and stays resident (the reference copies it >= 3 times per probe,
+    SURVEY.md §8a a6);
+  * built-in spectral functions are reduced on the device; Python callables are applied on the
+    host to the (P, deg) nodes.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable, Optional, Union
+
+import numpy as np
+from scipy.sparse.linalg import LinearOperator
+
+from . import engine
+from .lanczos import _as_device_operator
+from .special import builtin_spec, param_callable
+
+F64: np.dtype = np.dtype("float64")
+
+
+def _has_product(A: Any) -> bool:
+	return any(hasattr(A, a) for a in ("__matmul__", "matmul", "dot", "matvec"))
+
+
+def is_valid_operator(A: Union[np.ndarray, LinearOperator]) -> np.dtype:
+	"""Checks of operators.py:15-23; returns the floating dtype."""
+	assert _has_product(A), "Invalid operator; must have an overloaded 'matvec' or 'matmul' method"
+	assert hasattr(A, "shape") and len(A.shape) >= 2, "Operator must be at least two dimensional."
+	assert A.shape[0] == A.shape[1], "This function only works with square, symmetric matrices!"
+	f_dtype = (A @ np.zeros(A.shape[1])).dtype if not hasattr(A, "dtype") else A.dtype
+	assert np.dtype(f_dtype).type in {np.float32, np.float64}, "Only 32- or 64-bit floats are supported."
+	return np.dtype(f_dtype)
+
+
+def is_linear_op(A: Any) -> bool:
+	"""operators.py:26-33."""
+	return bool(_has_product(A) and hasattr(A, "shape") and len(A.shape) >= 2 and A.shape[0] == A.shape[1])
+
+
+class MatrixFunction(LinearOperator):
+	"""Linear operator approximating f(A) by degree-`deg` Lanczos (operators.py:36-151).
+
+	Parameters match the reference: A (ndarray / sparse / LinearOperator), fun (name or callable),
+	deg, orth (number of most recent Lanczos vectors to re-orthogonalise against; <0 or >deg means
+	deg), dtype, and **kwargs for the named function (e.g. t=, a=, b=, threshold=).
+	"""
+
+	def __init__(self, A, fun: Union[str, Callable, None] = None, deg: int = 20, orth: int = 3, dtype: np.dtype = F64, **kwargs) -> None:
+		assert is_linear_op(A), "Invalid operator `A`; must be dim=2 symmetric operator with defined matvec"
+		assert deg >= 2, "Degree must be >= 2"
+		self.shape = A.shape
+		self.dtype = np.dtype(dtype)
+		fun = (lambda x: x) if fun is None else fun
+		self._builtin = builtin_spec(fun, **kwargs) if isinstance(fun, str) else None
+		self.fun = param_callable(fun, **kwargs) if isinstance(fun, str) else fun
+		self._deg = min(deg, A.shape[0])
+		self._rtol = 1e-8
+		self._orth = self._deg if orth < 0 or orth > self._deg else orth
+		self._A = A
+		self._op = _as_device_operator(A, dtype=self.dtype)
+		self._plans: dict = {}
+		self._nodes = np.zeros(self._deg, dtype=self.dtype)
+		self._weights = np.zeros(self._deg, dtype=self.dtype)
+
+	@property
+	def degree(self) -> int:
+		return self._deg
+
+	@property
+	def fun(self) -> Callable:
+		return self._fun
+
+	@fun.setter
+	def fun(self, value: Callable) -> None:
+		assert callable(value), "Function must be callable."
+		out = value(np.ones(self.shape[1]))
+		assert isinstance(out, np.ndarray), "Function must return array-like"
+		assert out.shape[-1] == self.shape[0], "Last dimension of output must match number of rows."
+		self._fun = value
+		spec = getattr(value, "_slq_builtin", None)
+		if spec is not None:
+			self._builtin = spec
+		elif getattr(self, "_fun_initialised", False):
+			self._builtin = None
+		self._fun_initialised = True
+
+	def _adjoint(self):
+		return self
+
+	def _plan(self, nprobes: int, keep_basis: bool) -> engine.LanczosPlan:
+		key = (nprobes, keep_basis)
+		if key not in self._plans:
+			## one cached plan per shape class; older ones are released to bound device memory
+			for k in [k for k in self._plans if k[1] == keep_basis]:
+				self._plans.pop(k).close()
+			self._plans[key] = engine.LanczosPlan(self._op, nprobes, self._deg, self._orth, keep_basis=keep_basis)
+		return self._plans[key]
+
+	def quad(self, x: np.ndarray) -> np.ndarray:
+		"""x^T f(A) x for every column of x by Lanczos quadrature (operators.py:126-151)."""
+		x = np.asarray(x).astype(self.dtype)
+		x = np.atleast_2d(x).T if x.ndim == 1 else x
+		plan = self._plan(x.shape[1], False)
+		plan.set_probes(x)
+		plan.run(self._rtol)
+		if self._builtin is not None:
+			name, kw = self._builtin
+			y, nodes, weights = plan.quadrature(name, return_rule=True, **kw)
+		else:
+			y, nodes, weights = plan.quadrature(self._fun, return_rule=True)
+		## the reference leaves the last probe's rule in self._nodes/_weights (operators.py:149)
+		self._nodes[:], self._weights[:] = nodes[-1], weights[-1]
+		return y
+
+	def _matvec(self, x: np.ndarray) -> np.ndarray:
+		"""f(A) x ~= ||x|| Q Y (f(theta) * Y[0,:]) with the full Lanczos basis (operators.py:102-124)."""
+		return self._matmat(np.asarray(x).reshape(-1, 1))
+
+	def _matmat(self, X: np.ndarray) -> np.ndarray:
+		X = np.asarray(X).astype(self.dtype)
+		plan = self._plan(X.shape[1], True)
+		plan.set_probes(X)
+		plan.run(self._rtol)
+		if self._builtin is not None:
+			name, kw = self._builtin
+			return plan.fun_action(name, **kw)
+		## Python callable: nodes/eigenvectors on the host (k x k per probe), basis from the device
+		from scipy.linalg import eigh_tridiagonal
+
+		a, b, _ = plan.tridiag()
+		out = np.zeros((self.shape[0], X.shape[1]), dtype=self.dtype, order="F")
+		for i in range(X.shape[1]):
+			rw, Y = eigh_tridiagonal(a[i, : self._deg], b[i, 1 : self._deg])
+			coef = Y @ (np.ravel(self._fun(rw)) * Y[0, :])
+			out[:, i] = np.linalg.norm(X[:, i]) * (plan.basis(i) @ coef)
+		return out
+
+
+def matrix_function(A, fun: Optional[Callable] = None, v: Optional[np.ndarray] = None, deg: int = 20):
+	"""operators.py:155-161."""
+	M = MatrixFunction(A, fun=fun, deg=deg)
+	return M if v is None else M._matvec(v)

@@ -1,0 +1,170 @@
+"""The host-side mirror of the reference API (MatrixFunction / hutch / lanczos / quadrature) on
+the GPU: these read like the reference's own tests (tests/test_operator.py, test_trace.py,
+test_lanczos.py, test_quadrature.py in the reference tree) and also check golden driver outputs.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import laplacian_2d
+
+pytestmark = pytest.mark.gpu
+
+
+def spd(n, seed=1234, lo=None):
+	rng = np.random.default_rng(seed)
+	U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+	ew = rng.uniform(size=n, low=(1 / n if lo is None else lo), high=1.0)
+	A = (U * ew) @ U.T
+	return (A + A.T) / 2, ew
+
+
+def test_quad_form_matches_exact_quadratic_form():
+	## reference tests/test_operator.py:35-46
+	from primate_amd.operators import MatrixFunction
+
+	rng = np.random.default_rng(1234)
+	n = 100
+	A, _ = spd(n)
+	M = MatrixFunction(A, deg=n, orth=n, dtype=np.float64)
+	v = rng.uniform(size=n)
+	assert len(M.quad(v)) == 1
+	V = rng.uniform(size=(n, 10))
+	y1 = M.quad(V)
+	assert len(y1) == V.shape[1]
+	assert np.allclose(y1, np.diag(V.T @ A @ V))
+
+
+def test_operator_interface_and_builtin_functions():
+	## reference tests/test_operator.py:49-83
+	from scipy.sparse.linalg import LinearOperator, aslinearoperator
+
+	from primate_amd.operators import MatrixFunction, is_linear_op, matrix_function
+	from primate_amd.special import _BUILTIN_MATRIX_FUNCTIONS, param_callable
+
+	rng = np.random.default_rng(1234)
+	n = 100
+	A, _ = spd(n, lo=0.05)
+	v = rng.uniform(size=n, low=-1, high=1)
+	M = MatrixFunction(A, deg=n, orth=n, dtype=np.float64)
+	assert isinstance(M, LinearOperator) and is_linear_op(M) and M.degree == n
+	assert np.allclose(A @ v, M @ v)
+	assert np.allclose(A @ v, MatrixFunction(aslinearoperator(A), deg=n, orth=n) @ v)  # host-callback plugin
+	ew, ev = np.linalg.eigh(A)
+	for fun in _BUILTIN_MATRIX_FUNCTIONS:
+		f = param_callable(fun)
+		for F in (fun, f, lambda x, f=f: f(x)):  # name, tagged callable (device), opaque callable (host)
+			M = MatrixFunction(A, fun=F, deg=n)
+			assert np.allclose(ev @ np.diag(f(ew)) @ ev.T @ v, M @ v), fun
+	assert np.allclose(matrix_function(A, fun="exp", v=v, deg=n).ravel(), ev @ np.diag(np.exp(ew)) @ ev.T @ v)
+
+
+def test_hutch_matrix_function_identity():
+	## reference tests/test_trace.py:48-57: same seed, same count -> same estimate to 1e-6
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch
+
+	n = 50
+	A, _ = spd(n)
+	M = MatrixFunction(A, deg=n, orth=n)
+	est1 = hutch(A, converge="count", count=150, seed=1234)
+	est2 = hutch(M, converge="count", count=150, seed=1234)
+	assert np.isclose(est1, est2, atol=1e-6)
+
+
+def test_hutch_against_reference_driver_outputs(golden):
+	"""Golden: the reference's own hutch() on the same inputs ("pure" for plain arrays; "injected"
+	for MatrixFunction, with orth = 0 so the reference's stale-ring quirk does not enter)."""
+	from primate_amd.estimators import EstimatorResult
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch
+
+	assert hutch(golden["dense_A"], converge="count", count=64, seed=1234) == pytest.approx(float(golden["dense_hutch_c64"]), rel=1e-12)
+	assert hutch(golden["sym_A"], converge="count", count=150, seed=1234) == pytest.approx(float(golden["sym_hutch_c150"]), rel=1e-12)
+	M = MatrixFunction(golden["sym_A"], deg=50, orth=50)
+	assert hutch(M, converge="count", count=150, seed=1234) == pytest.approx(float(golden["sym_hutch_mf_c150"]), rel=1e-9)
+	## default stopping rule, full/callback surface (reference tests/test_trace.py:8-33)
+	A = golden["sym_A"]
+	est = hutch(A, seed=1234)
+	assert abs(A.trace() - est) <= 10 / np.sqrt(50)
+	est, info = hutch(A, seed=1234, full=True)
+	assert isinstance(info, EstimatorResult) and info.nit >= 3
+	calls = []
+	hutch(A, callback=lambda r: calls.append(r.nit), seed=5)
+	assert len(calls) > 0
+
+
+def test_hutch_slq_on_sparse_laplacian_matches_oracle_stream(oracle, golden):
+	"""hutch(MatrixFunction(L, "log")) with the reference's probe stream: per-sample values equal
+	the oracle's fresh-ring values on the very same probes, and the final estimate follows."""
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.random import isotropic
+	from primate_amd.trace import hutch
+
+	L = laplacian_2d(int(golden["lap_m"]))
+	for orth in (0, 3):
+		M = MatrixFunction(L, fun="log", deg=20, orth=orth)
+		est, info = hutch(M, converge="count", count=40, seed=1234, full=True, batch=8, record=True)
+		V = isotropic(size=(L.shape[0], 40), pdf="rademacher", seed=1234)
+		ref = oracle.quad_batch(L, V, 20, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(np.ravel(info.estimator.values), ref, rtol=1e-10)
+		assert est == pytest.approx(ref.mean(), rel=1e-12)
+		assert hutch(M, converge="count", count=40, seed=1234) == pytest.approx(ref.mean(), rel=1e-12)
+	## orth = 0: the reference driver's own number (injected golden; no stale-ring effect at orth 0)
+	M0 = MatrixFunction(L, fun="log", deg=20, orth=0)
+	ref0 = oracle.quad_batch(L, isotropic(size=(L.shape[0], 40), pdf="rademacher", seed=1234), 20, 0, fun="log", fresh_q=False)
+	assert hutch(M0, converge="count", count=40, seed=1234) == pytest.approx(ref0.mean(), rel=1e-12)
+
+
+def test_lanczos_and_rayleigh_ritz():
+	## reference tests/test_lanczos.py
+	from scipy.linalg import eigvalsh_tridiagonal
+
+	from primate_amd.lanczos import lanczos, rayleigh_ritz
+
+	rng = np.random.default_rng(seed=1234)
+	d = 50
+	A = rng.uniform(size=(d, d))
+	A @= A.T
+	v0 = rng.uniform(size=A.shape[1])
+	a, b = lanczos(A, v0=v0, deg=d, orth=d)
+	assert np.allclose(eigvalsh_tridiagonal(a, b), np.linalg.eigvalsh(A)), "Eigenvalues not similar"
+	A, ew = spd(d, lo=0.0)
+	v0 = rng.uniform(size=d)
+	rw = rayleigh_ritz(A, 20, v0=v0)
+	assert np.isclose(np.max(rw), np.max(ew), atol=1e-2) and np.isclose(np.min(rw), np.min(ew), atol=1e-2)
+	rw, rv = rayleigh_ritz(A, 20, v0=v0, return_eigenvectors=True)
+	assert np.allclose(rv.T @ rv, np.eye(len(rw)))
+	## lanczos-based f(A)v identity of tests/test_operator.py:10-32, deg = n and deg = 5 (A v in K_2)
+	A, _ = spd(100)
+	v = rng.uniform(size=100, low=-1, high=1)
+	for deg in (100, 5):
+		(a, b), Q = lanczos(A, v0=v, deg=deg, return_basis=True)
+		from scipy.linalg import eigh_tridiagonal
+
+		rw, Y = eigh_tridiagonal(a, b)
+		z = np.linalg.norm(v) * Q @ (Y @ (rw * Y[0, :]))
+		assert np.isclose(np.linalg.norm(z - A @ v), 0.0, atol=1e-8)
+
+
+def test_quadrature_api():
+	## reference tests/test_quadrature.py:7-20
+	from primate_amd.integrate import quadrature
+	from primate_amd.lanczos import lanczos
+
+	rng = np.random.default_rng(seed=1234)
+	A, _ = spd(50, lo=0.0)
+	ests = []
+	for _ in range(40):
+		v = rng.uniform(size=50, low=0, high=1)
+		v /= np.linalg.norm(v)
+		a, b = lanczos(A, deg=50, v0=v)
+		nodes, weights = quadrature(a, b, deg=30, quad="gw")
+		assert nodes.shape == (30,) and np.all(np.diff(nodes) >= 0) and abs(weights.sum() - 1) < 1e-10
+		ests.append(np.sum(nodes * weights))
+	assert abs(np.mean(ests) * 50 - A.trace()) <= 0.10 * A.trace()
+	out_n, out_w = np.zeros(30), np.zeros(30)
+	quadrature(a, np.append([0], b), deg=30, nodes=out_n, weights=out_w)
+	assert np.allclose(out_n, nodes) and np.allclose(out_w, weights)
+	with pytest.raises(ValueError):
+		quadrature(a, b, quad="nope")

@@ -1,0 +1,404 @@
+"""Parity of the HIP path with the oracle and with the golden vectors, through the C-ABI.
+
+Every test here needs a real MI355X (`-m gpu`). Nothing reads /root/reference. Tolerances: fp64
+per-probe quadratic forms 1e-10 relative against the oracle on identical probes (the north_star
+bar is 1e-6); fp32 2e-4; integer structure (steps, shapes, nnz, Rademacher support) bit-exact.
+"""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import laplacian_2d, laplacian_3d
+
+pytestmark = pytest.mark.gpu
+
+FUNS = {
+	"identity": {}, "log": {}, "exp": {}, "sqrt": {}, "inv": {}, "abs": {},
+	"smoothstep": {"a": 0.5, "b": 6.0}, "numrank": {},
+}  # fmt: skip
+
+
+@pytest.fixture(scope="module")
+def eng():
+	from primate_amd import engine
+
+	return engine
+
+
+@pytest.fixture(scope="module")
+def lap(golden, eng):
+	L = laplacian_2d(int(golden["lap_m"]))
+	return L, eng.DeviceOperator(L), golden["lap_probes"]
+
+
+def random_spd_graph(n, avg_deg, seed, dtype=np.float64):
+	"""Symmetric graph Laplacian + I of a G(n, p) graph: SPD, irregular row degrees, some empty rows."""
+	rng = np.random.default_rng(seed)
+	m = int(n * avg_deg / 2)
+	i, j = rng.integers(0, n, m), rng.integers(0, n, m)
+	keep = i != j
+	W = sp.coo_matrix((rng.uniform(0.5, 2.0, keep.sum()), (i[keep], j[keep])), shape=(n, n))
+	W = (W + W.T).tocsr()
+	W.sum_duplicates()
+	Lg = sp.diags(np.asarray(W.sum(axis=1)).ravel() + 1.0) - W
+	A = Lg.tocsr().astype(dtype)
+	A.sort_indices()
+	return A
+
+
+@pytest.mark.parametrize("orth", [0, 3, 20])
+def test_golden_laplacian_all_functions(lap, golden, eng, orth):
+	L, op, V = lap
+	for fun, kw in FUNS.items():
+		q = eng.quad_batch(op, V, 20, orth, fun=fun, **kw)
+		np.testing.assert_allclose(q, golden[f"lap_quad_{fun}_o{orth}"], rtol=1e-11, err_msg=fun)
+	q = eng.quad_batch(op, V, 20, orth, fun="exp", t=-0.1)
+	np.testing.assert_allclose(q, golden["lap_quad_exp_t_o%d" % orth], rtol=1e-11)
+
+
+@pytest.mark.parametrize("orth", [0, 3, 20])
+def test_golden_laplacian_tridiag_and_rule(lap, golden, eng, orth):
+	L, op, V = lap
+	plan = eng.LanczosPlan(op, V.shape[1], 20, orth)
+	plan.set_probes(V)
+	plan.run()
+	a, b, steps = plan.tridiag()
+	assert np.array_equal(steps, np.full(V.shape[1], 20))  # integer: bit-exact
+	np.testing.assert_allclose(a[:, :20], golden[f"lap_alpha_o{orth}"], rtol=0, atol=1e-12)
+	np.testing.assert_allclose(b[:, :20], golden[f"lap_beta_o{orth}"], rtol=0, atol=1e-12)
+	assert np.all(b[:, 0] == 0)
+	q, nodes, weights = plan.quadrature("log", return_rule=True)
+	np.testing.assert_allclose(nodes, golden[f"lap_nodes_o{orth}"], rtol=0, atol=1e-12)
+	np.testing.assert_allclose(weights, golden[f"lap_weights_o{orth}"], rtol=0, atol=1e-12)
+	np.testing.assert_allclose(weights.sum(axis=1), 1.0, atol=1e-13)
+
+
+def test_golden_kat_dense_full_reorth(golden, eng):
+	## inputs of the reference's tests/test_lanczos.py:11-20; dense operator plugin
+	A, v0 = golden["kat_A"], golden["kat_v0"]
+	op = eng.DeviceOperator(A)
+	plan = eng.LanczosPlan(op, 1, 50, 50, keep_basis=True)
+	plan.set_probes(v0)
+	plan.run()
+	a, b, steps = plan.tridiag()
+	assert steps[0] == 50
+	np.testing.assert_allclose(a[0, :50], golden["kat_alpha_o50_c50"], rtol=0, atol=1e-11 * np.abs(a).max())
+	np.testing.assert_allclose(b[0, :50], golden["kat_beta_o50_c50"], rtol=0, atol=1e-11 * np.abs(a).max())
+	Q = plan.basis(0)
+	np.testing.assert_allclose(np.abs(Q.T @ golden["kat_Q_o50_c50"]), np.eye(50), atol=1e-8)
+	np.testing.assert_allclose(Q.T @ Q, np.eye(50), atol=1e-10)
+	from scipy.linalg import eigvalsh_tridiagonal
+
+	assert np.allclose(eigvalsh_tridiagonal(a[0, :50], b[0, 1:50]), golden["kat_eigvalsh"])
+
+
+def test_golden_early_stop(golden, eng):
+	op = eng.DeviceOperator(golden["stop_A"])
+	plan = eng.LanczosPlan(op, 1, 20, 20)
+	plan.set_probes(golden["stop_v"])
+	plan.run()
+	a, b, steps = plan.tridiag()
+	assert steps[0] == 5  # lanczos.h:140-142, bit-exact step count
+	np.testing.assert_allclose(b[0, :5], golden["stop_beta"][:5], rtol=1e-10)
+	np.testing.assert_allclose(a[0, :5], golden["stop_alpha"][:5], rtol=1e-10)
+	assert b[0, 5] < np.sqrt(40) * 1e-8 and np.all(b[0, 6:] == 0) and np.all(a[0, 5:] == 0)
+	## the quadrature of the zero-tailed T equals v^T A v (f = identity)
+	q = plan.quadrature("identity")
+	v = golden["stop_v"]
+	np.testing.assert_allclose(q[0], v @ golden["stop_A"] @ v, rtol=1e-10)
+
+
+def test_c2_anchor_full_size(golden, eng):
+	"""BASELINE.json configs[1] at full size, one probe: the reference twin's value for the
+	seed-1234 Rademacher probe, plus the bit-exact integer structure."""
+	from primate_amd.random import isotropic
+
+	L2 = laplacian_2d(1000)
+	assert [L2.nnz, L2.shape[0]] == list(golden["c2_nnz_n"])
+	assert list(np.bincount(np.diff(L2.indptr))) == list(golden["c2_rowdeg_hist"])
+	op = eng.DeviceOperator(L2)
+	assert (op.shape, op.nnz) == ((1000000, 1000000), 4996000)
+	v = isotropic(pdf="rademacher", seed=1234)(size=(L2.shape[0], 1))
+	for k, orth in enumerate([0, 3]):
+		q = eng.quad_batch(op, v, 30, orth, fun="log")
+		assert abs(q[0] / golden["c2_quad_log_seed1234_o0_o3"][k] - 1) < 1e-10
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-10), (np.float32, 3e-4)])
+@pytest.mark.parametrize("orth", [0, 3, 25])
+def test_oracle_random_graph_ragged(oracle, eng, dtype, rtol, orth):
+	## irregular degrees, empty-ish rows, n not a multiple of anything, ragged probe count
+	A = random_spd_graph(2003, 6.0, seed=11, dtype=dtype)
+	rng = np.random.default_rng(5)
+	X = np.asfortranarray(rng.standard_normal((A.shape[0], 37)).astype(dtype))
+	op = eng.DeviceOperator(A)
+	for fun, kw in [("log", {}), ("exp", {"t": -0.05}), ("sqrt", {})]:
+		got = eng.quad_batch(op, X, 25, orth, fun=fun, **kw)
+		ref = oracle.quad_batch(A, X, 25, orth, fun=fun, fresh_q=True, prefer="csr", **kw)
+		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"{fun} orth={orth}")
+
+
+@pytest.mark.parametrize("nprobes", [1, 2, 15, 16, 17, 64, 129, 300])
+def test_probe_count_edges(oracle, eng, nprobes):
+	## every panel geometry (PW = 16..128, one or several panels, ragged last panel)
+	A = laplacian_2d(17)
+	rng = np.random.default_rng(nprobes)
+	X = np.asfortranarray(np.floor(rng.random((A.shape[0], nprobes)) * 2) * 2 - 1)
+	op = eng.DeviceOperator(A)
+	got = eng.quad_batch(op, X, 12, 3, fun="log")
+	ref = oracle.quad_batch(A, X, 12, 3, fun="log", fresh_q=True)
+	np.testing.assert_allclose(got, ref, rtol=1e-10)
+
+
+def test_tiny_and_degenerate_operators(oracle, eng):
+	## n smaller than deg (deg clamps to n, lanczos.py:79), n = 2, diagonal matrix with a zero row
+	for n in [2, 3, 7]:
+		A = sp.diags(np.arange(1.0, n + 1)).tocsr()
+		X = np.asfortranarray(np.ones((n, 3)) + np.arange(3))
+		got = eng.quad_batch(eng.DeviceOperator(A), X, 20, 0, fun="identity")
+		np.testing.assert_allclose(got, np.einsum("ij,ij->j", X, A @ X), rtol=1e-10)
+	A = sp.csr_matrix(np.diag([2.0, 0.0, 3.0, 1.0]))  # row 1 is empty
+	X = np.asfortranarray(np.array([[1.0, 2.0, -1.0, 0.5]]).T)
+	got = eng.quad_batch(eng.DeviceOperator(A), X, 4, 4, fun="identity")
+	np.testing.assert_allclose(got, X[:, 0] @ (A @ X[:, 0]), rtol=1e-10)
+	## an all-zero probe is 0/0 in the reference (lanczos.h:120): NaN, and its neighbours are untouched
+	A = laplacian_2d(5)
+	X = np.asfortranarray(np.ones((25, 3)))
+	X[:, 1] = 0
+	got = eng.quad_batch(eng.DeviceOperator(A), X, 10, 3, fun="identity")
+	assert np.isnan(got[1]) and np.allclose(got[[0, 2]], np.ones(25) @ (A @ np.ones(25)))
+
+
+def test_operator_products(eng):
+	rng = np.random.default_rng(8)
+	A = random_spd_graph(501, 5.0, seed=3)
+	X = np.asfortranarray(rng.standard_normal((501, 21)))
+	ref = A @ X
+	np.testing.assert_allclose(eng.DeviceOperator(A).matmat(X), ref, rtol=1e-12, atol=1e-12)
+	np.testing.assert_allclose(eng.DeviceOperator(A.toarray()).matmat(X), ref, rtol=1e-11, atol=1e-11)
+
+	class PyOp:  # the Python plugin surface (pylinop.h:22-29): .matvec + .shape (+ dtype)
+		shape, dtype = A.shape, np.dtype(np.float64)
+		calls = 0
+
+		def matvec(self, v):
+			PyOp.calls += 1
+			return A @ v
+
+	np.testing.assert_allclose(eng.DeviceOperator(PyOp()).matmat(X), ref, rtol=1e-12, atol=1e-12)
+	assert PyOp.calls == 21
+	A32 = A.astype(np.float32)
+	np.testing.assert_allclose(eng.DeviceOperator(A32).matmat(X.astype(np.float32)), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_all_three_operator_kinds_agree_on_slq(oracle, eng):
+	A = laplacian_2d(12)
+	rng = np.random.default_rng(2)
+	X = np.asfortranarray(rng.standard_normal((144, 5)))
+	ref = oracle.quad_batch(A, X, 15, 3, fun="log", fresh_q=True)
+
+	class PyOp:
+		shape, dtype = A.shape, np.dtype(np.float64)
+
+		def matvec(self, v):
+			return A @ v
+
+	for M in [A, A.toarray(), PyOp()]:
+		got = eng.quad_batch(eng.DeviceOperator(M), X, 15, 3, fun="log")
+		np.testing.assert_allclose(got, ref, rtol=1e-10)
+
+	class Broken:
+		shape, dtype = A.shape, np.dtype(np.float64)
+
+		def matvec(self, v):
+			raise KeyError("boom")
+
+	with pytest.raises(KeyError):
+		eng.quad_batch(eng.DeviceOperator(Broken()), X, 5, 0, fun="log")
+
+
+def test_fun_action_against_dense_eigendecomposition(eng, golden):
+	## reference tests/test_operator.py:72-83 style: M @ v == U f(L) U^T v for deg = n
+	rng = np.random.default_rng(1234)
+	n = 60
+	B = rng.standard_normal((n, n))
+	A = B @ B.T / n + 0.5 * np.eye(n)
+	ew, ev = np.linalg.eigh(A)
+	X = np.asfortranarray(rng.uniform(-1, 1, (n, 4)))
+	op = eng.DeviceOperator(A)
+	plan = eng.LanczosPlan(op, 4, n, n, keep_basis=True)
+	for fun, kw, f in [("identity", {}, lambda x: x), ("log", {}, np.log), ("exp", {"t": -0.3}, lambda x: np.exp(-0.3 * x)), ("inv", {}, lambda x: 1 / x), ("sqrt", {}, np.sqrt)]:
+		plan.set_probes(X)
+		plan.run()
+		Y = plan.fun_action(fun, **kw)
+		np.testing.assert_allclose(Y, (ev * f(ew)) @ ev.T @ X, rtol=1e-8, atol=1e-9, err_msg=fun)
+	## golden (injected): the reference's MatrixFunction._matvec on the Laplacian
+	L = laplacian_2d(int(golden["lap_m"]))
+	V = golden["lap_probes"][:, :4]
+	plan = eng.LanczosPlan(eng.DeviceOperator(L), 4, 20, 20, keep_basis=True)
+	plan.set_probes(V)
+	plan.run()
+	np.testing.assert_allclose(plan.fun_action("exp", t=-0.1), golden["mf_matvec_exp_t"], rtol=1e-9, atol=1e-10)
+
+
+def test_standalone_quadrature_entry(eng, golden, oracle):
+	d, e = golden["tri_d"], golden["tri_e"]
+	nodes, weights = eng.quadrature_batch(d[None, :], e[None, :])
+	np.testing.assert_allclose(nodes[0], golden["tri_nodes"], rtol=0, atol=1e-13)
+	np.testing.assert_allclose(weights[0], golden["tri_weights"], rtol=0, atol=1e-13)
+	## reference tests/test_tridiagonal.py:26-44: d = 150, eigenvalues within 1e-14 of LAPACK
+	from scipy.linalg import eigvalsh_tridiagonal
+
+	D, E = [], []
+	for seed in [1234, 4756, 43, 102]:
+		rng = np.random.default_rng(seed)
+		D.append(rng.uniform(size=150))
+		E.append(np.append([0.0], rng.uniform(size=149, low=0.0, high=0.5)))
+	nodes, weights = eng.quadrature_batch(np.array(D), np.array(E))
+	for i in range(4):
+		assert np.max(np.abs(nodes[i] - eigvalsh_tridiagonal(D[i], E[i][1:]))) <= 2e-14
+		np.testing.assert_allclose(weights[i].sum(), 1.0, atol=1e-13)
+
+
+def test_single_vector_dropin_entry(oracle, eng, golden):
+	"""slq_lanczos_f64: same in/out contract as primate._lanczos.lanczos (_lanczos.cpp:88-99)."""
+	from primate_amd.lanczos import _native_lanczos, lanczos
+
+	L = laplacian_2d(int(golden["lap_m"]))
+	v = golden["lap_probes"][:, 0]
+	for orth, ncv in [(0, 2), (3, 3), (3, 20), (20, 20), (5, 7)]:
+		al, be, Q = np.zeros(21), np.zeros(21), np.zeros((L.shape[0], ncv), order="F")
+		al2, be2, Q2 = np.zeros(21), np.zeros(21), np.zeros((L.shape[0], ncv), order="F")
+		steps = _native_lanczos(L, v, 20, 1e-8, orth, al, be, Q)
+		steps2 = oracle.lanczos(L, v, 20, 1e-8, orth, al2, be2, Q2)
+		assert steps == steps2 == 20
+		np.testing.assert_allclose(al, al2, rtol=1e-9, atol=1e-12)
+		np.testing.assert_allclose(be, be2, rtol=1e-9, atol=1e-12)
+		np.testing.assert_allclose(Q, Q2, rtol=0, atol=1e-9)  # same ring columns, same content
+	## the public API, against vectors captured from the reference's lanczos() (injected)
+	for orth, rb in [(0, False), (5, False), (-1, False), (3, True)]:
+		res = lanczos(L, v0=v.copy(), deg=20, orth=orth, return_basis=rb)
+		(a, b) = res[0] if rb else res
+		np.testing.assert_allclose(a, golden[f"api_alpha_o{orth}_rb{int(rb)}"], rtol=1e-9)
+		np.testing.assert_allclose(b, golden[f"api_beta_o{orth}_rb{int(rb)}"], rtol=1e-9)
+		if rb:
+			np.testing.assert_allclose(res[1], golden[f"api_Q_o{orth}_rb1"], atol=1e-9)
+
+
+def test_device_probe_generator(eng):
+	## reference tests/test_random.py:6-20 properties, on the Philox generator
+	A = laplacian_2d(40)  # n = 1600
+	op = eng.DeviceOperator(A)
+	n = A.shape[0]
+	plan = eng.LanczosPlan(op, 200, 4, 0)
+	plan.generate_probes("rademacher", seed=7)
+	R = plan.get_probes()
+	assert set(np.unique(R)) == {-1.0, 1.0}  # exact support
+	assert abs(R.mean()) < 5 / np.sqrt(R.size) and np.max(np.abs(R.T @ R / n - np.eye(200))) < 0.2
+	plan.generate_probes("normal", seed=7)
+	Gs = plan.get_probes()
+	from scipy.stats import normaltest
+
+	assert normaltest(Gs.ravel()).pvalue >= 0.001 and abs(Gs.std() - 1) < 0.01
+	plan.generate_probes("sphere", seed=7)
+	S = plan.get_probes()
+	plan.run()
+	q = plan.quadrature("identity")
+	## sphere probes: direction g/||g||, norm^2 = n exactly (random.py:36-41)
+	Sn = S / np.linalg.norm(S, axis=0) * np.sqrt(n)
+	np.testing.assert_allclose(q, np.einsum("ij,ij->j", Sn, A @ Sn), rtol=1e-10)
+	## same (seed, id) -> same probe, whatever the batch shape or offset
+	p1 = eng.LanczosPlan(op, 200, 4, 0)
+	p1.generate_probes("rademacher", seed=7)
+	p2 = eng.LanczosPlan(op, 50, 4, 0)
+	p2.generate_probes("rademacher", seed=7, probe_offset=100)
+	assert np.array_equal(p1.get_probes()[:, 100:150], p2.get_probes())
+	p2.generate_probes("rademacher", seed=8, probe_offset=100)
+	assert not np.array_equal(p1.get_probes()[:, 100:150], p2.get_probes())
+
+
+def test_full_size_properties_c2(eng):
+	"""BASELINE configs[1] at full size, 256 device probes: size-independent checks."""
+	L2 = laplacian_2d(1000)
+	op = eng.DeviceOperator(L2)
+	n = L2.shape[0]
+	logdet = 1166809.9080624094  # closed form, BASELINE.md §2
+	plan = eng.LanczosPlan(op, 256, 30, 3)
+	plan.generate_probes("rademacher", seed=1234)
+	plan.run()
+	q = plan.quadrature("log")
+	assert abs(q.mean() - logdet) < 6 * q.std(ddof=1) / np.sqrt(256)  # unbiased within 6 sigma
+	assert abs(q.mean() / logdet - 1) < 2e-3
+	## identity: sum f(theta) tau ||v||^2 with f = 1 is ||v||^2 = n exactly for Rademacher probes
+	plan.generate_probes("rademacher", seed=1234)
+	plan.run()
+	qi, nodes, weights = plan.quadrature("identity", return_rule=True)
+	np.testing.assert_allclose(weights.sum(axis=1), 1.0, atol=1e-12)
+	assert nodes.min() > 0 and nodes.max() < 8  # spectrum of the Dirichlet Laplacian
+	a, b, steps = plan.tridiag()
+	assert np.all(steps == 30)
+	## trace(A) estimate is exact for Rademacher probes on a matrix with constant diagonal 4:
+	## v^T A v = 4n - 2 * (number of +1 neighbours minus -1 ...) varies; check first moment
+	np.testing.assert_allclose(a[:, 0] * n, qi, rtol=1e-12)  # alpha_0 = v^T A v / ||v||^2
+	## sharding independence: two half-batches with offsets reproduce the batch bitwise
+	plan.generate_probes("rademacher", seed=1234)
+	plan.run()
+	q_all = plan.quadrature("log")
+	half = eng.LanczosPlan(op, 128, 30, 3)
+	parts = []
+	for off in (0, 128):
+		half.generate_probes("rademacher", seed=1234, probe_offset=off)
+		half.run()
+		parts.append(half.quadrature("log"))
+	assert np.array_equal(np.concatenate(parts), q_all)
+	## orth = 0 / 3 / 30 agree far below the 1e-6 bar on the same probes
+	p0 = eng.LanczosPlan(op, 16, 30, 0)
+	p0.generate_probes("rademacher", seed=1234)
+	p0.run()
+	np.testing.assert_allclose(p0.quadrature("log"), q_all[:16], rtol=1e-10)
+
+
+def test_3d_laplacian_north_star_variant(oracle, eng):
+	## the north_star's "nnz~7M" operator at reduced size (3D 7-point), oracle parity incl. full reorth
+	A = laplacian_3d(14)
+	rng = np.random.default_rng(3)
+	X = np.asfortranarray(np.floor(rng.random((A.shape[0], 9)) * 2) * 2 - 1)
+	op = eng.DeviceOperator(A)
+	for orth in [0, 3, 30]:
+		got = eng.quad_batch(op, X, 30, orth, fun="log")
+		ref = oracle.quad_batch(A, X, 30, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(got, ref, rtol=1e-10)
+
+
+def test_abi_error_behaviour(eng):
+	from primate_amd import _capi
+
+	A = laplacian_2d(6)
+	op = eng.DeviceOperator(A)
+	with pytest.raises(ValueError):
+		eng.LanczosPlan(op, 0, 5, 0)
+	with pytest.raises(ValueError):
+		eng.LanczosPlan(op, 4, 0, 0)
+	plan = eng.LanczosPlan(op, 4, 5, 0)
+	with pytest.raises(ValueError):
+		plan.run()  # no probes yet
+	with pytest.raises(ValueError):
+		plan.tridiag()
+	with pytest.raises(ValueError):
+		plan.basis(0)  # no keep_basis
+	with pytest.raises(AssertionError):
+		eng.DeviceOperator(sp.random(5, 6, 0.5).tocsr())
+	with pytest.raises(AssertionError):
+		eng.DeviceOperator(A.astype(np.int32))
+	with pytest.raises(ValueError):
+		eng.DeviceOperator(type("NoMatvec", (), {"shape": (3, 3), "dtype": np.dtype(np.float64)})())
+	## malformed CSR is rejected by the library itself
+	import ctypes as C
+
+	rowptr = np.array([0, 2, 1], dtype=np.int32)
+	colind = np.array([0, 5], dtype=np.int32)
+	vals = np.ones(2)
+	h = C.c_void_p()
+	rc = _capi.lib().slq_csr_create(op.ctx._h, _capi.SLQ_F64, 2, 2, _capi.ptr(rowptr), _capi.ptr(colind), _capi.ptr(vals), C.byref(h))
+	assert rc == _capi.SLQ_EINVAL and b"rowptr" in _capi.lib().slq_last_error()

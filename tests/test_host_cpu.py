@@ -1,0 +1,192 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports what include/slq.h declares, host
+logic (function registry, probe stream, estimators, hutch bookkeeping, byte model), and the
+world_size-2 gloo rehearsal of the probe-sharded reduction."""
+
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+	import __graft_entry__ as g
+	from primate_amd import _capi
+
+	g.build_libslq()
+	hdr = (ROOT / "include" / "slq.h").read_text()
+	hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+	declared = set(re.findall(r"\b(slq_[a-z0-9_]+)\s*\(", hdr)) - {"slq_matvec_fn"}
+	assert len(declared) >= 30
+	L = _capi.lib()
+	missing = [s for s in declared if not hasattr(L, s)]
+	assert not missing, missing
+	assert declared == set(_capi.EXPORTED_SYMBOLS), declared ^ set(_capi.EXPORTED_SYMBOLS)
+	assert L.slq_version() == 100
+
+
+def test_no_gpu_fails_loudly_not_silently():
+	import torch
+
+	if torch.cuda.is_available():
+		pytest.skip("a GPU is visible")
+	from primate_amd import _capi, engine
+
+	with pytest.raises(_capi.SlqError) as ei:
+		engine.Context(device=0)
+	assert ei.value.code == _capi.SLQ_ENODEV and "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+	for p in (ROOT / "primate_amd").rglob("*"):
+		if p.suffix in {".py", ".hip", ".hpp", ".h"}:
+			txt = p.read_text()
+			assert "import oracle" not in txt and "from oracle" not in txt and "slq_oracle" not in txt, p
+
+
+def test_function_registry_matches_golden(golden):
+	from primate_amd.engine import fun_spec
+	from primate_amd.special import _BUILTIN_MATRIX_FUNCTIONS, builtin_spec, param_callable
+
+	x = golden["fun_x"]
+	with np.errstate(all="ignore"):
+		for name, kw in [("identity", {}), ("log", {}), ("exp", {}), ("sqrt", {}), ("inv", {}), ("abs", {}), ("smoothstep", {"a": 0.5, "b": 6.0}), ("numrank", {}), ("softsign", {"q": 10})]:
+			f = param_callable(name, **dict(kw))
+			r, ref = np.asarray(f(x), dtype=float), golden[f"fun_{name}"]
+			ok = np.isfinite(ref)
+			assert np.array_equal(r[ok], ref[ok]), name
+			assert builtin_spec(f)[0] == name
+		assert np.array_equal(param_callable("exp", t=-0.1)(x), golden["fun_exp_t"])
+	assert _BUILTIN_MATRIX_FUNCTIONS == ["identity", "abs", "sqrt", "log", "inv", "exp", "smoothstep", "numrank"]
+	assert fun_spec("numrank")[0] == 7 and list(fun_spec("numrank")[1][:2]) == [1e-6, 1.0]
+	assert fun_spec("exp", t=-2.0)[1][0] == -2.0 and fun_spec(np.log) == (None, None)
+	with pytest.raises(AssertionError):
+		param_callable("nope")
+
+
+def test_probe_stream_order_contract(golden):
+	from primate_amd.random import isotropic
+
+	for pdf in ["rademacher", "normal", "sphere"]:
+		a = isotropic((37, 5), pdf=pdf, seed=1234)
+		assert np.array_equal(a, golden[f"iso_{pdf}_37x5_s1234"]) and a.flags["F_CONTIGUOUS"] and a.dtype == np.float64
+		g = isotropic(pdf=pdf, seed=99)
+		b = np.column_stack([g(size=(11, 1)), g(size=(11, 2)), g(size=(11, 1))])
+		assert np.array_equal(b, golden[f"iso_{pdf}_seq_s99"])
+	assert set(np.unique(isotropic((50, 4), pdf="signs", seed=1))) == {-1.0, 1.0}
+	assert np.allclose(np.linalg.norm(isotropic((50, 4), pdf="sphere", seed=1), axis=0), np.sqrt(50))
+	with pytest.raises(AssertionError):
+		isotropic((3, 3), pdf="cauchy")
+
+
+def test_streaming_estimator_and_merge(golden):
+	from primate_amd.estimators import ConfidenceCriterion, CountCriterion, Covariance, MeanEstimator, ToleranceCriterion, convergence_criterion
+
+	xs, tr = golden["est_samples"], golden["est_trail"]
+	cov, est = Covariance(1), MeanEstimator(covariance=True)
+	for k, (lo, hi) in enumerate([(0, 1), (1, 9), (9, 41), (41, 57)]):
+		cov.update(xs[lo:hi])
+		est.update(xs[lo:hi])
+		assert np.array_equal([cov.n, cov.mu.item(), cov.S.item(), est.estimate, np.ravel(est.delta)[0]], tr[k])
+	assert len(est) == 57 and np.isclose(cov.covariance(), np.var(xs, ddof=1))
+	a, b, c = Covariance(1), Covariance(1), Covariance(1)
+	a.update(xs[:20]); b.update(xs[20:]); c.update(xs)  # noqa: E702
+	a.merge(b.n, b.mu, b.S)
+	assert a.n == c.n and np.allclose(a.mu, c.mu, rtol=1e-14) and np.allclose(a.S, c.S, rtol=1e-12)
+	cc = CountCriterion(10) | ConfidenceCriterion(0.95, atol=1e-9, rtol=0.0)
+	e2 = MeanEstimator(covariance=True)
+	assert not cc(e2)
+	e2.update(np.arange(10.0))
+	assert cc(e2) and not (~cc)(e2) and not (cc & ToleranceCriterion(rtol=0, atol=0))(e2)
+	assert isinstance(convergence_criterion("count", count=3, junk=1), CountCriterion)
+
+
+def test_hutch_bookkeeping_without_a_gpu(golden):
+	"""hutch() on plain arrays never touches the device: checks the sample-at-a-time semantics
+	against the reference's own outputs ("pure" golden)."""
+	from primate_amd.trace import hutch
+
+	assert hutch(golden["dense_A"], converge="count", count=64, seed=1234) == pytest.approx(float(golden["dense_hutch_c64"]), rel=1e-13)
+	assert hutch(golden["sym_A"], converge="count", count=150, seed=1234) == pytest.approx(float(golden["sym_hutch_c150"]), rel=1e-13)
+
+	class FakeQuad:  # an operator exposing .quad, as trace.py:97 prefers
+		shape, dtype = (20, 20), np.dtype(np.float64)
+		seen = []
+
+		def __matmul__(self, v):
+			return v
+
+		def quad(self, V):
+			FakeQuad.seen.append(V.shape[1])
+			return np.einsum("ij,ij->j", V, V)
+
+	est, info = hutch(FakeQuad(), converge="count", count=70, seed=0, full=True, batch=32)
+	assert est == 20.0 and info.nit == 96 and FakeQuad.seen == [32, 32, 32]
+	FakeQuad.seen.clear()
+	assert hutch(FakeQuad(), converge="count", count=70, seed=0) == 20.0 and sum(FakeQuad.seen) == 70
+
+
+def test_bench_byte_model():
+	sys.path.insert(0, str(ROOT))
+	import bench
+
+	n, nnz, s, b = 1_000_000, 4_996_000, 8, 256
+	## SURVEY.md §8(d) figures: 64.25 MB per probe-matvec at orth = 0, b = 256
+	B0 = bench.contract_bytes_per_probe_matvec(n, nnz, s, b, 5, 0)
+	assert abs(B0 - (64e6 + (12 * nnz + 4 * (n + 1)) / 256)) < 1 and abs(B0 / 1e6 - 64.25) < 0.01
+	assert bench.contract_bytes_per_probe_matvec(n, nnz, s, b, 10, 3) == pytest.approx(112e6 + 0.25e6, rel=1e-3)
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0)
+	assert kl == {"spmm_3term": 30, "axpy_norm": 31, "reorth_dot": 0, "reorth_update": 0}
+	vec = s * n * b
+	assert kb["spmm_3term"] == 30 * 2 * (12 * nnz + 4 * (n + 1)) + (2 + 29 * 3) * vec
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 30)
+	assert kl["reorth_dot"] == 30 + 14 and kl["reorth_update"] == 30
+	assert kb["reorth_update"] == sum(min(j + 1, 30) + 2 for j in range(30)) * vec
+
+
+def test_shard_ranges_cover_and_are_disjoint():
+	from primate_amd.distributed import shard_range
+
+	for P in [1, 7, 256, 2048]:
+		for W in [1, 2, 3, 8]:
+			r = [shard_range(P, k, W) for k in range(W)]
+			assert r[0][0] == 0 and r[-1][1] == P and all(r[k][1] == r[k + 1][0] for k in range(W - 1))
+			assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+_GLOO_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from primate_amd.distributed import allreduce_trace, allreduce_sum, shard_range, local_statistics, merge_statistics
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(42)
+allq = rng.standard_normal(257) * 5 + 100          # stands in for the per-probe quad values
+lo, hi = shard_range(len(allq), rank, world)
+n, mu, var = allreduce_trace(allq[lo:hi])
+n2, mu2, var2, xs = allreduce_trace(allq[lo:hi], gather_samples=True)
+tot = allreduce_sum(np.full(5, rank + 1.0))
+ok = (n == 257 and abs(mu - allq.mean()) < 1e-12 and abs(var - allq.var(ddof=1)) < 1e-10
+      and np.array_equal(xs, allq) and mu2 == merge_statistics(local_statistics(allq))[1]
+      and np.array_equal(tot, np.full(5, world * (world + 1) / 2)))
+print("RANK", rank, "OK" if ok else "FAIL", n, mu, var)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_sharded_reduce_world2_gloo(tmp_path):
+	script = tmp_path / "worker.py"
+	script.write_text(_GLOO_WORKER)
+	env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
+	procs = [subprocess.Popen([sys.executable, str(script), str(ROOT)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+	outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+	assert all(p.returncode == 0 for p in procs), outs
+	assert all("OK" in o for o in outs), outs
