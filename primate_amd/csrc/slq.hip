@@ -686,6 +686,12 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
 
 static int launch_reorth_update(slq_plan *p, int j, int r);
 
+// probes per workgroup of the QL kernel: 3*deg*lanes doubles of LDS, at most 150 KiB
+static int quadrature_lanes(int deg) {
+  int lanes = (int)((150 * 1024) / ((size_t)3 * deg * 8));
+  return std::max(1, std::min(64, lanes));
+}
+
 extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!p) return fail(SLQ_EINVAL, "plan is NULL");
   if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
@@ -792,16 +798,13 @@ extern "C" int slq_plan_quadrature(slq_plan *p, int fun_id, const double *fun_pa
   hipStream_t st = p->ctx->stream;
   const int deg = p->deg, P = p->nprobes;
   const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
-  const size_t lds = (size_t)3 * deg * 64 * 8;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  const int lanes = quadrature_lanes(deg);
+  const size_t lds = (size_t)3 * deg * lanes * 8;
+  if (lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_quadrature, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip tridiagonal solver", deg);
   HIP_TRY(hipMemsetAsync(p->fail_d, 0, sizeof(int), st));
   PROFILED(p, SLQ_K_QUADRATURE,
-           hipLaunchKernelGGL(k_quadrature, dim3((P + 63) / 64), dim3(64), lds, st, p->st, fun_id, p0, p1,
+           hipLaunchKernelGGL(k_quadrature, dim3((P + lanes - 1) / lanes), dim3(64), lds, st, p->st, lanes, fun_id, p0, p1,
                               p->quad_d, (nodes ? p->nodes_d : nullptr), (weights ? p->weights_d : nullptr), p->fail_d));
   HIP_TRY(hipGetLastError());
   int bad = 0;
@@ -909,8 +912,8 @@ extern "C" int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const dou
   if (!ctx || !d || !e) return fail(SLQ_EINVAL, "ctx/d/e is NULL");
   if (nb <= 0 || deg <= 0 || deg > kMaxDeg) return fail(SLQ_EINVAL, "bad batch size or degree");
   if (fun_id < SLQ_FUN_NONE || fun_id > SLQ_FUN_SOFTSIGN) return fail(SLQ_EINVAL, "Unknown function id %d.", fun_id);
-  const size_t lds = (size_t)3 * deg * 64 * 8;
-  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip tridiagonal solver", deg);
+  const int lanes = quadrature_lanes(deg);
+  const size_t lds = (size_t)3 * deg * lanes * 8;
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int bp = (nb + 63) / 64 * 64;
@@ -944,7 +947,7 @@ extern "C" int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const dou
   }
   if (err == hipSuccess) {
     const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
-    k_quadrature<<<dim3((nb + 63) / 64), dim3(64), lds, st>>>(s, fun_id, p0, p1, dq, dn, dw, dfail);
+    k_quadrature<<<dim3((nb + lanes - 1) / lanes), dim3(64), lds, st>>>(s, lanes, fun_id, p0, p1, dq, dn, dw, dfail);
     err = hipGetLastError();
   }
   int bad = 0;

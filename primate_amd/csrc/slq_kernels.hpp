@@ -671,26 +671,29 @@ __device__ __forceinline__ double apply_fun(int fun_id, double p0, double p1, do
   }
 }
 
-// One probe per lane; d, e, z live in LDS as [k][64] so a wave's accesses are conflict-free.
+// One probe per lane; d, e, z live in LDS as [k][lanes] so a wave's accesses are conflict-free.
 // Implicit-shift QL (Wilkinson shift) carrying only the first row of the eigenvector matrix:
 // nodes = eigenvalues of T_k, weights = z^2 (Golub-Welsch; reference: integrate.py:61-64 via
 // LAPACK stemr, tridiag.py:10-11). Nodes are sorted ascending like LAPACK's output.
 // T_k is the full deg x deg Jacobi matrix with a zero tail after an early stop — what the
 // reference sees with freshly allocated alpha/beta (lanczos.py:101-102).
-__global__ __launch_bounds__(64) void k_quadrature(StepState st, int fun_id, double p0, double p1,
-                                                   double *__restrict__ quad,
+__global__ __launch_bounds__(64) void k_quadrature(StepState st, int lanes, int fun_id, double p0,
+                                                   double p1, double *__restrict__ quad,
                                                    double *__restrict__ nodes,
                                                    double *__restrict__ weights,
                                                    int *__restrict__ fail) {
   extern __shared__ double lds[];
   const int k = st.deg;
   const int lane = threadIdx.x;
-  const int col = blockIdx.x * 64 + lane;
-  double *d = lds + lane, *e = lds + k * 64 + lane, *z = lds + 2 * k * 64 + lane;
-#define D(i) d[(i) * 64]
-#define E(i) e[(i) * 64]
-#define Z(i) z[(i) * 64]
-  const bool live = col < st.nprobes;
+  // `lanes` <= 64 probes per workgroup: the LDS stride, chosen by the host so 3*k*lanes doubles fit
+  const int col = blockIdx.x * lanes + lane;
+  const int ll = lane < lanes ? lane : 0;
+  double *d = lds + ll, *e = lds + k * lanes + ll, *z = lds + 2 * k * lanes + ll;
+#define D(i) d[(i) * lanes]
+#define E(i) e[(i) * lanes]
+#define Z(i) z[(i) * lanes]
+  const bool live = lane < lanes && col < st.nprobes;
+  if (!live) return;
   for (int i = 0; i < k; ++i) {
     D(i) = live ? st.alpha[(int64_t)i * st.bpad + col] : 0.0;
     // E(i) couples i and i+1: beta_{i+1} = nu[i+1]
