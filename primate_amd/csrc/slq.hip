@@ -429,17 +429,20 @@ static int ring_slots(int deg, int orth, int keep_basis) {
   return std::max(orth + 1, 3);
 }
 
-static void grid_sizes(int n, int LPR, int num_cus, int *nblkA, int *nblkS) {
+static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nblkS) {
   const int RPW = 64 / LPR;
   const int rows_per_block = kWaves * RPW;
-  const int per_cu = std::max(1, env_int("SLQ_BLOCKS_PER_CU", 2));
-  const int cap = std::max(8, num_cus * per_cu);
+  // Tunables: resident workgroups (kBlock threads) per CU, summed over the panels of a launch.
+  // Defaults from the MI355X sweeps: in-place read-modify-write sweeps peak at
+  // ~2 workgroups per CU (more concurrent writers lose 5-10 %); the SpMM likes 4-8.
+  const int per_cu_a = std::max(1, env_int("SLQ_BLOCKS_PER_CU_SPMM", env_int("SLQ_BLOCKS_PER_CU", 8)));
+  const int per_cu_s = std::max(1, env_int("SLQ_BLOCKS_PER_CU_STREAM", env_int("SLQ_BLOCKS_PER_CU", 2)));
   // sweep A: a multiple of 8 blocks (XCD-aware chunking), no more than the rows can feed
   const int chunk = (n + 7) / 8;
-  int per_xcd = std::min(cap / 8, (chunk + rows_per_block - 1) / rows_per_block);
+  int per_xcd = std::min(std::max(8, num_cus * per_cu_a / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   per_xcd = std::max(per_xcd, 1);
   *nblkA = 8 * per_xcd;
-  int s = std::min(cap, (n + rows_per_block * 4 - 1) / (rows_per_block * 4));
+  int s = std::min(std::max(1, num_cus * per_cu_s / NP), (n + rows_per_block - 1) / rows_per_block);
   *nblkS = std::max(s, 1);
 }
 
@@ -497,7 +500,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->S = ring_slots(deg, orth, p->keep_basis);
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
-  grid_sizes(p->n, p->LPR, ctx->num_cus, &p->nblkA, &p->nblkS);
+  grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS);
   memset(&p->acc, 0, sizeof(p->acc));
   memset(&p->st, 0, sizeof(p->st));
 
@@ -568,7 +571,7 @@ static int init_from_probes(slq_plan *p, int sphere) {
                                         (F *)slot_ptr(p, 0), (const F *)nullptr,
                                         (const double *)nullptr, p->part, p->bpad))));
   PROFILED(p, SLQ_K_FINALIZE,
-           hipLaunchKernelGGL(k_fin_init, dim3((p->bpad + 63) / 64), dim3(256), 0, st, p->st, p->part,
+           hipLaunchKernelGGL(k_fin_init, dim3((p->bpad + 63) / 64), dim3(kFinThreads), 0, st, p->st, p->part,
                               p->nblkS, sphere, (double)p->n));
   HIP_TRY(hipGetLastError());
   p->probes_ready = true;
@@ -718,7 +721,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
                                             (const F *)slot_ptr(p, sc_), (const F *)slot_ptr(p, sp_),
                                             (F *)slot_ptr(p, sn_), p->st.coefA, p->part, bp, first))));
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(256), 0, st, p->st, p->part, p->nblkA, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
     } else {
       SLQ_TRY(apply_operator_unfused(p, sc_));
       PROFILED(p, SLQ_K_AXPY_NORM,
@@ -728,7 +731,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
                                             (const F *)slot_ptr(p, sp_), (F *)slot_ptr(p, sn_),
                                             p->st.coefA, p->part, bp, first))));
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(256), 0, st, p->st, p->part, p->nblkS, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j));
     }
     const int r = p->orth > 0 ? std::min(j + 1, p->orth) : 0;
     if (r == 0) {
@@ -746,13 +749,13 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
                                               (F *)p->ring, p->slot_stride, S, j, i0, rc, (int)(i0 == 0),
                                               p->st.coefB, p->part, bp))));
         PROFILED(p, SLQ_K_FINALIZE,
-                 hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(256), 0, st, p->st,
+                 hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i0, orth_tol));
       }
       SLQ_TRY(launch_reorth_update(p, j, r));
     }
     PROFILED(p, SLQ_K_FINALIZE,
-             hipLaunchKernelGGL(k_fin_beta, gF, dim3(256), 0, st, p->st, p->part, p->nblkS, j, residual_tol));
+             hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j, residual_tol));
   }
   HIP_TRY(hipGetLastError());
   p->probes_ready = false;

@@ -32,7 +32,10 @@ template <> struct VecT<float> {
 constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
 constexpr int kWaves = kBlock / 64;
 constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
-constexpr int kMaxDeg = 512;         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
+constexpr int kMaxDeg = 512;
+#ifndef SLQ_UPD_UR
+#define SLQ_UPD_UR 2
+#endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
 
 template <typename F, int LPR> struct Geo {
   static constexpr int V = VecT<F>::V;
@@ -246,7 +249,6 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
                                                       double *__restrict__ partN, int bpad) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
-  constexpr int UR = 4;
   __shared__ double red[kWaves * 64 * V];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
@@ -259,30 +261,18 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
     for (int v = 0; v < V; ++v) cb[v] = (F)coefB[colbase + v];
   }
   VF nacc = (VF)(F)0;
+  // One row per wave per iteration, consecutive waves on consecutive rows: the grid sweeps one
+  // contiguous window. (Unrolling over far-apart rows, i.e. several windows a power of two apart,
+  // measured 25 % SLOWER on MI355X: scripts/microbench_stream.hip.)
   const int stride = gridDim.x * kWaves * RPW;
-  for (int r0 = (blockIdx.x * kWaves + wave) * RPW + g; r0 < n; r0 += UR * stride) {
-    VF w[UR], q[UR];
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const int row = r0 + u * stride;
-      if (row < n) {
-        const int64_t ro = poff + (int64_t)row * PW;
-        w[u] = *(const VF *)(W + ro);
-        if (MODE == 0) q[u] = *(const VF *)(Wc + ro);
-      }
+  for (int row = (blockIdx.x * kWaves + wave) * RPW + g; row < n; row += stride) {
+    const int64_t ro = poff + (int64_t)row * PW;
+    VF x = *(const VF *)(W + ro);
+    if (MODE == 0) {
+      x -= cb * *(const VF *)(Wc + ro);
+      *(VF *)(W + ro) = x;
     }
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const int row = r0 + u * stride;
-      if (row < n) {
-        VF x = w[u];
-        if (MODE == 0) {
-          x -= cb * q[u];
-          *(VF *)(W + poff + (int64_t)row * PW) = x;
-        }
-        nacc += x * x;
-      }
-    }
+    nacc += x * x;
   }
   block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
 }
@@ -352,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
     double *__restrict__ partN, int bpad) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
-  constexpr int UR = 4;
+  constexpr int UR = SLQ_UPD_UR;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double *red = (double *)lds_raw;                       // kWaves*64*V doubles
   F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V); // r * PW
@@ -366,13 +356,15 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
   VF nacc = (VF)(F)0;
-  const int stride = gridDim.x * kWaves * RPW;
-  for (int r0 = (blockIdx.x * kWaves + wave) * RPW + g; r0 < n; r0 += UR * stride) {
+  // UR CONSECUTIVE row groups per wave and iteration (one contiguous UR*RPW*PW*sizeof(F) block):
+  // the gamma read from LDS is amortised over UR rows and UR loads per column are in flight.
+  const int stride = gridDim.x * kWaves * RPW * UR;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW * UR + g; r0 < n; r0 += stride) {
     VF w[UR];
     int64_t ro[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const int row = r0 + u * stride;
+      const int row = r0 + u * RPW;
       ro[u] = (int64_t)(row < n ? row : 0) * PW;
       w[u] = *(const VF *)(W + ro[u]);
     }
@@ -387,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const int row = r0 + u * stride;
+      const int row = r0 + u * RPW;
       if (row < n) {
         *(VF *)(W + ro[u]) = w[u];
         nacc += w[u] * w[u];
@@ -410,24 +402,38 @@ struct StepState {
   int bpad, nprobes, deg;
 };
 
-// Sum part[blk][col] over blk in a fixed order. Block = 256 threads = 64 columns x 4 slices.
+// Sum part[blk][col] over blk in a fixed order. Block = kFinThreads = 64 columns x kFinSlices
+// slices; each thread adds every kFinSlices-th partial (4 independent loads in flight), then the
+// slices are folded through LDS in slice order: bitwise reproducible.
+constexpr int kFinSlices = 16;
+constexpr int kFinThreads = 64 * kFinSlices;
 __device__ __forceinline__ double sum_partials(const double *__restrict__ part, int nblk, int bpad,
-                                               int col, double *red4 /* 256 doubles */) {
+                                               int col, double *red /* kFinThreads doubles */) {
   const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
-  double acc = 0.0;
-  if (col < bpad)
-    for (int b = s; b < nblk; b += 4) acc += part[(int64_t)b * bpad + col];
-  red4[s * 64 + c] = acc;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (col < bpad) {
+    int b = s;
+    for (; b + 3 * kFinSlices < nblk; b += 4 * kFinSlices) {
+      a0 += part[(int64_t)b * bpad + col];
+      a1 += part[(int64_t)(b + kFinSlices) * bpad + col];
+      a2 += part[(int64_t)(b + 2 * kFinSlices) * bpad + col];
+      a3 += part[(int64_t)(b + 3 * kFinSlices) * bpad + col];
+    }
+    for (; b < nblk; b += kFinSlices) a0 += part[(int64_t)b * bpad + col];
+  }
+  red[s * 64 + c] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  double tot = red4[c] + red4[64 + c] + red4[128 + c] + red4[192 + c];
+  double tot = 0.0;
+#pragma unroll
+  for (int k = 0; k < kFinSlices; ++k) tot += red[k * 64 + c];
   __syncthreads();
   return tot;
 }
 
 // After the probe-norm sweep: nu_0 = ||v||, first coefficients, activity flags.
-__global__ __launch_bounds__(256) void k_fin_init(StepState st, const double *__restrict__ partN,
+__global__ __launch_bounds__(kFinThreads) void k_fin_init(StepState st, const double *__restrict__ partN,
                                                   int nblk, int sphere, double n_as_double) {
-  __shared__ double red4[256];
+  __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const double s = sum_partials(partN, nblk, st.bpad, col, red4);
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
@@ -444,9 +450,9 @@ __global__ __launch_bounds__(256) void k_fin_init(StepState st, const double *__
 }
 
 // After sweep A of step j: alpha_j, and the sweep-B coefficient cB = alpha_j / nu_j.
-__global__ __launch_bounds__(256) void k_fin_alpha(StepState st, const double *__restrict__ partA,
+__global__ __launch_bounds__(kFinThreads) void k_fin_alpha(StepState st, const double *__restrict__ partA,
                                                    int nblk, int j) {
-  __shared__ double red4[256];
+  __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const double a = sum_partials(partA, nblk, st.bpad, col, red4);
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
@@ -457,9 +463,9 @@ __global__ __launch_bounds__(256) void k_fin_alpha(StepState st, const double *_
 }
 
 // After the last sweep of step j: beta_{j+1} = ||w||, stop rule (lanczos.h:139-142), next sc/cp.
-__global__ __launch_bounds__(256) void k_fin_beta(StepState st, const double *__restrict__ partN,
+__global__ __launch_bounds__(kFinThreads) void k_fin_beta(StepState st, const double *__restrict__ partN,
                                                   int nblk, int j, double residual_tol) {
-  __shared__ double red4[256];
+  __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const double s = sum_partials(partN, nblk, st.bpad, col, red4);
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
@@ -482,9 +488,9 @@ __global__ __launch_bounds__(256) void k_fin_beta(StepState st, const double *__
 
 // After a sweep-B chunk: gamma_i = (W_t . w) / nu_t^2 unless |q_t . w| <= 2 eps sqrt(n)
 // (lanczos.h:53,62: the projection is skipped when it is below the orthogonality tolerance).
-__global__ __launch_bounds__(256) void k_fin_gamma(StepState st, const double *__restrict__ partD,
+__global__ __launch_bounds__(kFinThreads) void k_fin_gamma(StepState st, const double *__restrict__ partD,
                                                    int nblk, int j, int i0, double orth_tol) {
-  __shared__ double red4[256];
+  __shared__ double red4[kFinThreads];
   const int i = blockIdx.y;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const double d = sum_partials(partD + (int64_t)i * nblk * st.bpad, nblk, st.bpad, col, red4);
