@@ -59,9 +59,17 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 	return ((s + 4) * nnz + 4 * (n + 1)) / b + (8 + 2 * r) * s * n
 
 
-def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16):
-	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each vector panel is
-	read or written once per sweep, the CSR arrays once per panel of `pw` probes."""
+FUSED_MAX_R = 4  # slq_kernels.hpp:kFusedMaxR
+
+
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
+	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each
+	vector panel a kernel touches is read or written once, the CSR arrays once per panel of `pw`
+	probes. Two launch sequences exist per Lanczos step (slq.hip:slq_plan_run):
+	  fused (CSR, r_j <= 4): the SpMM is recomputed in each pass and only the last pass writes —
+	    alpha pass [spmm_3term], dots pass [reorth_dot], update pass [reorth_update | axpy_norm];
+	  store-and-revisit (deeper reorthogonalisation): spmm_3term writes w, then reorth_dot /
+	    reorth_update (or axpy_norm) revisit it in place."""
 	npan = math.ceil(b / pw)
 	vec = s * n * b
 	csr = npan * ((s + 4) * nnz + 4 * (n + 1))
@@ -70,9 +78,20 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16):
 	out["axpy_norm"] += vec  # ||v||^2 of the probes
 	launches["axpy_norm"] += 1
 	for j in range(deg):
+		r = 0 if orth == 0 else min(j + 1, orth)
+		if fused and r <= FUSED_MAX_R:
+			rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
+			out["spmm_3term"] += csr + (1 if j == 0 else 2) * vec
+			launches["spmm_3term"] += 1
+			if r > 0:
+				out["reorth_dot"] += csr + rd * vec
+				launches["reorth_dot"] += 1
+			k = "reorth_update" if r > 0 else "axpy_norm"
+			out[k] += csr + (rd + 1) * vec
+			launches[k] += 1
+			continue
 		out["spmm_3term"] += csr + (2 if j == 0 else 3) * vec  # gather q_c, read q_p, write w
 		launches["spmm_3term"] += 1
-		r = 0 if orth == 0 else min(j + 1, orth)
 		if r == 0:
 			out["axpy_norm"] += 3 * vec  # read w, q_c; write w
 			launches["axpy_norm"] += 1
@@ -178,7 +197,8 @@ def main():
 
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
 	pw = 128 if P > 64 else (64 if P > 32 else (32 if P > 16 else 16))
-	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth)
+	fused = os.environ.get("SLQ_FUSED", "1") != "0"
+	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, fused=fused)
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)
 	launches = prof[dom]["launches"]
@@ -218,7 +238,7 @@ def main():
 		"config": {
 			"workload": f"configs[1]: logdet via SLQ, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={args.fun}",
 			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
-			"parallelism": f"probe-sharded x{world}, operator replicated",
+			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused),
 		},
 		"trace_estimates_per_s": round(world * P * args.steps / elapsed, 1),
 		"estimate": float(estimate),

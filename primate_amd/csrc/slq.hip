@@ -508,7 +508,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t bp = p->bpad;
   // alpha[deg+1], nu[deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
   const size_t nscal = ((size_t)(deg + 1) * 2 + 1 + 2 + 1 + (size_t)p->rmax) * bp;
-  const size_t npart = (size_t)std::max(p->nblkA, kReorthChunk * p->nblkS) * bp;
+  const size_t npart = (size_t)kReorthChunk * std::max(p->nblkA, p->nblkS) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
@@ -687,7 +687,8 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
   return SLQ_OK;
 }
 
-static int launch_reorth_update(slq_plan *p, int j, int r);
+static int launch_reorth_update(slq_plan *p, int j, int r, int istart);
+static int update_chunk_cols(const slq_plan *p);
 
 // probes per workgroup of the QL kernel: 3*deg*lanes doubles of LDS, at most 150 KiB
 static int quadrature_lanes(int deg) {
@@ -710,16 +711,55 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
   const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gF((bp + 63) / 64);
   const slq_operator *op = p->op;
+  const bool fused = env_int("SLQ_FUSED", 1) != 0;  // recompute-SpMM passes (default) vs store-and-revisit sweeps
+  const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
   for (int j = 0; j < deg; ++j) {
     const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
     const int first = (j == 0);
+    const int r = p->orth > 0 ? std::min(j + 1, p->orth) : 0;
+    int nblk_last = p->nblkS;
+    if (op->kind == OP_CSR && fused && r <= kFusedMaxR) {
+      // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
+      const int V = p->dtype == SLQ_F64 ? 2 : 4;
+      const size_t lds0 = sizeof(double) * kWaves * 64 * V;
+#define CSR_PASS(PASS, LP, SP, I0, RC, LDS)                                                          \
+  DISPATCH(p->dtype, p->LPR,                                                                         \
+           (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<gA, dim3(kBlock), LDS, st>>>(                           \
+               p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, S,   \
+               j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp)))
+      PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, lds0); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, lds0); });
+      PROFILED(p, SLQ_K_FINALIZE,
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
+      if (r > 0) {
+        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0); });
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
+                                    p->part, p->nblkA, j, 0, orth_tol));
+      }
+      const size_t ldsU = lds0 + (size_t)r * p->PW * p->esz;
+      PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
+               { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU); });
+#undef CSR_PASS
+      nblk_last = p->nblkA;
+    } else {
     if (op->kind == OP_CSR) {
-      PROFILED(p, SLQ_K_SPMM,
-               DISPATCH(p->dtype, p->LPR,
-                        (k_spmm_3term<F, L><<<gA, dim3(kBlock), 0, st>>>(p->n,
-                                            op->rowptr, op->colind, (const F *)op->vals,
-                                            (const F *)slot_ptr(p, sc_), (const F *)slot_ptr(p, sp_),
-                                            (F *)slot_ptr(p, sn_), p->st.coefA, p->part, bp, first))));
+      const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
+#define SPMM_LAUNCH(LP, SP)                                                                          \
+  DISPATCH(p->dtype, p->LPR,                                                                         \
+           (k_spmm_3term<F, L, LP, SP><<<gA, dim3(kBlock), 0, st>>>(                                 \
+               p->n, op->rowptr, op->colind, (const F *)op->vals, (const F *)slot_ptr(p, sc_),       \
+               (const F *)slot_ptr(p, sp_), (F *)slot_ptr(p, sn_), p->st.coefA, p->part, bp, first)))
+      PROFILED(p, SLQ_K_SPMM, {
+        switch (pol) {
+          case 1: SPMM_LAUNCH(0, 1); break;
+          case 2: SPMM_LAUNCH(0, 2); break;
+          case 10: SPMM_LAUNCH(1, 0); break;
+          case 11: SPMM_LAUNCH(1, 1); break;
+          case 12: SPMM_LAUNCH(1, 2); break;
+          default: SPMM_LAUNCH(0, 0); break;
+        }
+      });
+#undef SPMM_LAUNCH
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
     } else {
@@ -733,7 +773,6 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j));
     }
-    const int r = p->orth > 0 ? std::min(j + 1, p->orth) : 0;
     if (r == 0) {
       PROFILED(p, SLQ_K_AXPY_NORM,
                DISPATCH(p->dtype, p->LPR,
@@ -752,10 +791,11 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i0, orth_tol));
       }
-      SLQ_TRY(launch_reorth_update(p, j, r));
+      SLQ_TRY(launch_reorth_update(p, j, r, 0));
     }
+    }  // !fused
     PROFILED(p, SLQ_K_FINALIZE,
-             hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j, residual_tol));
+             hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, nblk_last, j, residual_tol));
   }
   HIP_TRY(hipGetLastError());
   p->probes_ready = false;
@@ -851,12 +891,12 @@ static int update_chunk_cols(const slq_plan *p) {
 }
 
 // w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
-static int launch_reorth_update(slq_plan *p, int j, int r) {
+static int launch_reorth_update(slq_plan *p, int j, int r, int istart) {
   hipStream_t st = p->ctx->stream;
   const int V = p->dtype == SLQ_F64 ? 2 : 4;
   const int kUpdChunk = update_chunk_cols(p);
   const dim3 gS(p->nblkS, p->NP);
-  for (int i0 = 0; i0 < r; i0 += kUpdChunk) {
+  for (int i0 = istart; i0 < r; i0 += kUpdChunk) {
     const int rc = std::min(kUpdChunk, r - i0);
     const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
     if (lds > 48 * 1024) {
@@ -900,7 +940,7 @@ extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_pa
   // output accumulates in slot `deg` (the spare slot behind the basis; it held the last residual)
   HIP_TRY(hipMemsetAsync(slot_ptr(p, deg), 0, (size_t)p->slot_stride * p->esz, st));
   // the update kernel walks t = (deg-1) - i for i = 0..deg-1: k_fun_coeffs stored g_t in row deg-1-t
-  SLQ_TRY(launch_reorth_update(p, deg - 1, deg));
+  SLQ_TRY(launch_reorth_update(p, deg - 1, deg, 0));
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));

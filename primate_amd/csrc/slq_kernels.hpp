@@ -29,10 +29,33 @@ template <> struct VecT<float> {
   static constexpr int V = 4;
 };
 
+// ---- cache-policy helpers ---------------------------------------------------------------------
+// Streamed-once panel rows should not evict the gather window from the XCD's 4 MiB L2.
+// POLICY 0: plain; 1: nontemporal hint (global_load/store ... nt);
+// stores only, 2: write-through-and-drop (global_store ... sc1; MI355X_MICROARCH.md 'stores of each
+// flavour': sc1 stores do not keep the line in L2).
+template <int POLICY, typename VF> __device__ __forceinline__ VF stream_load(const VF *p) {
+  if (POLICY == 1) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <int POLICY> __device__ __forceinline__ void stream_store(
+    double __attribute__((ext_vector_type(2))) * p, double __attribute__((ext_vector_type(2))) v) {
+  if (POLICY == 1) __builtin_nontemporal_store(v, p);
+  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+template <int POLICY> __device__ __forceinline__ void stream_store(
+    float __attribute__((ext_vector_type(4))) * p, float __attribute__((ext_vector_type(4))) v) {
+  if (POLICY == 1) __builtin_nontemporal_store(v, p);
+  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+
 constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
 constexpr int kWaves = kBlock / 64;
 constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
 constexpr int kMaxDeg = 512;
+constexpr int kFusedMaxR = 4;        // fused recompute passes handle up to this many reorth columns
 #ifndef SLQ_UPD_UR
 #define SLQ_UPD_UR 2
 #endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
@@ -79,7 +102,7 @@ __device__ __forceinline__ void block_reduce_columns(const typename VecT<F>::typ
 // [x*n/8, (x+1)*n/8) with all of its waves interleaved row by row: the set of rows in flight is a
 // narrow band whose stencil neighbours stay L2-resident, and each panel row is fetched from HBM
 // about once per XCD.
-template <typename F, int LPR>
+template <typename F, int LPR, int LP, int SP>
 __global__ __launch_bounds__(kBlock) void k_spmm_3term(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
     const F *__restrict__ vals, const F *Wc, const F *Wp, F *Wn, const double *__restrict__ coefA,
@@ -134,12 +157,144 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
       const int64_t ro = (int64_t)row * PW;
       const VF xc = *(const VF *)(wc + ro);
       VF w = sc * acc;
-      if (!first) w -= cp * *(const VF *)(wp + ro);
+      if (!first) w -= cp * stream_load<LP>((const VF *)(wp + ro));
       aacc += (sc * xc) * w;
-      *(VF *)(wn + ro) = w;
+      stream_store<SP>((VF *)(wn + ro), w);
     }
   }
   block_reduce_columns<F, LPR>(aacc, red, partA + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- fused CSR passes: the SpMM is RECOMPUTED row-locally in every pass, never stored ----------
+// Writes cost ~1.6x reads on MI355X HBM, and the intermediate vector
+// u = A q_c - beta_j q_p of a Lanczos step is needed only row-locally by everything that follows
+// (alpha = q_c.u, w' = u - alpha q_c, the reorthogonalisation dots and the final update). So
+// instead of storing u (sweep A) and re-reading/re-writing it (sweeps B, C), each pass re-derives
+// u[row] from the gather — bitwise the same value every time — and only the last pass writes:
+//   PASS_ALPHA   partA += (sc*Wc[row]) * u[row]                               reads: Wc (gather), Wp
+//   PASS_DOTS    w' = u - cB*Wc[row]; partD[i] += W_{t_i}[row] * w'           reads: + r ring columns
+//   PASS_UPDATE  w'' = u - cB*Wc[row] - sum_i gamma_i W_{t_i}[row]; store; partN += w''^2
+// Per step that is (2 + 2 max(r,2)) panel reads + 1 write (r > 0) or 4 reads + 1 write (r = 0)
+// against (2r + 4) reads + 3 writes / 4 reads + 2 writes for the store-and-revisit sweeps.
+// Ring columns t_0 = j (W_c) and t_1 = j-1 (W_p) are the rows the three-term part loads anyway.
+// DCH = compile-time capacity for ring columns per launch (registers); the host uses these passes
+// for r <= kFusedMaxR and the store-and-revisit sweeps (k_reorth_dot / k_reorth_update) for deeper
+// reorthogonalisation, where the saved write no longer pays for re-gathering (measured).
+enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2 };
+
+template <typename F, int LPR, int PASS, int LP, int SP, int DCH>
+__global__ __launch_bounds__(kBlock) void k_csr_pass(
+    int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+    const F *__restrict__ vals, F *ring, int64_t slot_stride, int S, int j, int i0, int rc,
+    const double *__restrict__ coefA, const double *__restrict__ coefB,
+    const double *__restrict__ gamma /* PASS_UPDATE: [rc][bpad] */, double *__restrict__ part,
+    int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double *red = (double *)lds_raw;                                 // kWaves*64*V doubles
+  F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);       // PASS_UPDATE: rc * PW
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int first = (j == 0);
+  const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
+  F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *U0 = ring + poff;
+  const int colbase = panel * PW + cl * V;
+  VF sc, cp, cb = (VF)(F)0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    sc[v] = (F)coefA[colbase + v];
+    cp[v] = (F)coefA[bpad + colbase + v];
+    if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
+  }
+  if (PASS == PASS_UPDATE) {
+    for (int t = threadIdx.x; t < rc * PW; t += kBlock)
+      gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+    __syncthreads();
+  }
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
+  const int chunk = (n + 7) / 8;
+  const int r_begin = xcd * chunk;
+  const int r_end = min(n, r_begin + chunk);
+  const int stride = nbl * kWaves * RPW;
+  VF acc1 = (VF)(F)0;  // alpha or norm partial
+  VF dacc[PASS == PASS_DOTS ? DCH : 1];
+  if (PASS == PASS_DOTS) {
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) dacc[i] = (VF)(F)0;
+  }
+  for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
+    int row = r0 + g;
+    if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+    if (row < r_end) {
+      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+      const int64_t ro = (int64_t)row * PW;
+      // row-local operands first: their latency overlaps the dependent colind -> gather chain
+      const VF xc = *(const VF *)(wc + ro);
+      VF xp = (VF)(F)0;
+      if (!first) xp = stream_load<LP>((const VF *)(wp + ro));
+      VF acc = (VF)(F)0;
+      int p = p0;
+      for (; p + 4 <= p1; p += 4) {
+        const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
+        const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
+        const VF x0 = *(const VF *)(wc + (int64_t)c0 * PW);
+        const VF x1 = *(const VF *)(wc + (int64_t)c1 * PW);
+        const VF x2 = *(const VF *)(wc + (int64_t)c2 * PW);
+        const VF x3 = *(const VF *)(wc + (int64_t)c3 * PW);
+        acc += a0 * x0;
+        acc += a1 * x1;
+        acc += a2 * x2;
+        acc += a3 * x3;
+      }
+      for (; p < p1; ++p) {
+        const int c = colind[p];
+        const F a = vals[p];
+        acc += a * *(const VF *)(wc + (int64_t)c * PW);
+      }
+      VF w = sc * acc;
+      if (!first) w -= cp * xp;
+      if (PASS == PASS_ALPHA) {
+        acc1 += (sc * xc) * w;
+      } else {
+        w -= cb * xc;
+        // ring columns of this launch: ii = i0 + i; ii = 0 is W_c (xc), ii = 1 is W_p (xp)
+        VF u[DCH];
+#pragma unroll
+        for (int i = 0; i < DCH; ++i)
+          if (i < rc) {
+            const int ii = i0 + i;
+            u[i] = (ii == 0) ? xc
+                             : ((ii == 1) ? xp
+                                          : stream_load<LP>((const VF *)(U0 + (int64_t)((j - ii) % S) * slot_stride + ro)));
+          }
+        if (PASS == PASS_DOTS) {
+#pragma unroll
+          for (int i = 0; i < DCH; ++i)
+            if (i < rc) dacc[i] += u[i] * w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < DCH; ++i)
+            if (i < rc) w -= *(const VF *)(gl + i * PW + cl * V) * u[i];
+          stream_store<SP>((VF *)(wn + ro), w);
+          acc1 += w * w;
+        }
+      }
+    }
+  }
+  const int64_t nblk = gridDim.x;
+  if (PASS == PASS_DOTS) {
+#pragma unroll
+    for (int i = 0; i < DCH; ++i)
+      if (i < rc)
+        block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+  } else {
+    block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+  }
 }
 
 // ---- plain panel SpMM: Y = A X (operator plugin surface; also the dense/CSR matmat entry) -------

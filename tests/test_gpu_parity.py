@@ -341,7 +341,9 @@ def test_full_size_properties_c2(eng):
 	## trace(A) estimate is exact for Rademacher probes on a matrix with constant diagonal 4:
 	## v^T A v = 4n - 2 * (number of +1 neighbours minus -1 ...) varies; check first moment
 	np.testing.assert_allclose(a[:, 0] * n, qi, rtol=1e-12)  # alpha_0 = v^T A v / ||v||^2
-	## sharding independence: two half-batches with offsets reproduce the batch bitwise
+	## sharding independence: two half-batches with offsets reproduce the batch (the
+	## probes are bitwise the same; the block partition of the reductions depends on the panel count,
+	## so the values agree to rounding, not bitwise)
 	plan.generate_probes("rademacher", seed=1234)
 	plan.run()
 	q_all = plan.quadrature("log")
@@ -351,7 +353,10 @@ def test_full_size_properties_c2(eng):
 		half.generate_probes("rademacher", seed=1234, probe_offset=off)
 		half.run()
 		parts.append(half.quadrature("log"))
-	assert np.array_equal(np.concatenate(parts), q_all)
+	np.testing.assert_allclose(np.concatenate(parts), q_all, rtol=1e-13)
+	half.generate_probes("rademacher", seed=1234, probe_offset=128)
+	half.run()
+	assert np.array_equal(half.quadrature("log"), parts[1])  # same configuration: bitwise reproducible
 	## orth = 0 / 3 / 30 agree far below the 1e-6 bar on the same probes
 	p0 = eng.LanczosPlan(op, 16, 30, 0)
 	p0.generate_probes("rademacher", seed=1234)

@@ -140,13 +140,23 @@ def test_bench_byte_model():
 	B0 = bench.contract_bytes_per_probe_matvec(n, nnz, s, b, 5, 0)
 	assert abs(B0 - (64e6 + (12 * nnz + 4 * (n + 1)) / 256)) < 1 and abs(B0 / 1e6 - 64.25) < 0.01
 	assert bench.contract_bytes_per_probe_matvec(n, nnz, s, b, 10, 3) == pytest.approx(112e6 + 0.25e6, rel=1e-3)
-	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0)
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=False)
 	assert kl == {"spmm_3term": 30, "axpy_norm": 31, "reorth_dot": 0, "reorth_update": 0}
 	vec = s * n * b
-	assert kb["spmm_3term"] == 30 * 2 * (12 * nnz + 4 * (n + 1)) + (2 + 29 * 3) * vec
-	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 30)
+	csr = 2 * (12 * nnz + 4 * (n + 1))
+	assert kb["spmm_3term"] == 30 * csr + (2 + 29 * 3) * vec
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 30, fused=False)
 	assert kl["reorth_dot"] == 30 + 14 and kl["reorth_update"] == 30
 	assert kb["reorth_update"] == sum(min(j + 1, 30) + 2 for j in range(30)) * vec
+	## fused passes (r <= 4): alpha pass reads 2 panels, update pass reads 2 (+r-2) and writes 1
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=True)
+	assert kl == {"spmm_3term": 30, "axpy_norm": 31, "reorth_dot": 0, "reorth_update": 0}
+	assert kb["spmm_3term"] == 30 * csr + (1 + 29 * 2) * vec and kb["axpy_norm"] == vec + 30 * csr + (2 + 29 * 3) * vec
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 3, fused=True)
+	assert kl["reorth_dot"] == 30 and kb["reorth_dot"] == 30 * csr + (1 + 2 + 28 * 3) * vec
+	## deeper reorthogonalisation falls back to the store-and-revisit sweeps once r_j > 4
+	kb5, kl5 = bench.kernel_bytes(n, nnz, s, b, 128, 30, 30, fused=True)
+	assert kl5["reorth_dot"] == 30 + 14
 
 
 def test_shard_ranges_cover_and_are_disjoint():
