@@ -75,6 +75,7 @@ enum { SLQ_PDF_RADEMACHER = 0, SLQ_PDF_NORMAL = 1, SLQ_PDF_SPHERE = 2 };
 typedef struct slq_context slq_context;   /* one per (process, GPU): device id + HIP stream      */
 typedef struct slq_operator slq_operator; /* a symmetric linear operator resident on that GPU    */
 typedef struct slq_plan slq_plan;         /* workspace + state of one batched Lanczos run        */
+typedef struct slq_diag slq_diag;         /* device-resident accumulators of the diagonal estimator */
 
 /* Host-callback operator: y = A x on HOST memory (the fallback for arbitrary Python
  * LinearOperators; mirrors PyLinearOperator::matvec, src/primate/include/pylinop.h:32-40).
@@ -161,6 +162,21 @@ int slq_plan_fun_action(slq_plan *plan, int fun_id, const double *fun_params, vo
 int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e,
                          int fun_id, const double *fun_params, double *quad, double *nodes,
                          double *weights);
+
+/* FTTR quadrature weights on the device (integrate.quadrature(..., quad="fttr"),
+ * src/primate/integrate.py:65-69 -> src/primate/fttr.py:17-29): theta, weights are nb x k row-major;
+ * alpha, beta nb x n row-major (beta[:,0] unused); values as the reference's fttr() returns them. */
+int slq_fttr_batch(slq_context *ctx, int nb, int n, int k, const double *theta, const double *alpha,
+                   const double *beta, double *weights);
+
+/* Diagonal estimator (the loop body of diag(), src/primate/diagonal.py:74-79): for every probe of a
+ * completed keep_basis run, in order, numer += f(A)v * v, denom += v*v, and the running mean of
+ * numer/denom (the reference's estimate). Everything stays on the device between updates. */
+int slq_diag_create(slq_context *ctx, int64_t n, slq_diag **out);
+int slq_diag_destroy(slq_diag *d);
+int slq_diag_update(slq_diag *d, slq_plan *plan, int fun_id, const double *fun_params);
+/* any of numer / denom / running_mean (n doubles each) and count may be NULL */
+int slq_diag_get(slq_diag *d, double *numer, double *denom, double *running_mean, int64_t *count);
 
 /* Per-kernel device time accumulated by HIP events on the context stream (for bench.py's
  * roofline line). enable != 0 turns event recording on for subsequent slq_plan_run calls. */

@@ -69,6 +69,11 @@ _SIGNATURES = {
 	"slq_plan_get_basis": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
 	"slq_plan_fun_action": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
 	"slq_quadrature_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+	"slq_fttr_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+	"slq_diag_create": (C.c_int, [_P, C.c_int64, _PP]),
+	"slq_diag_destroy": (C.c_int, [_P]),
+	"slq_diag_update": (C.c_int, [_P, _P, C.c_int, _P]),
+	"slq_diag_get": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64)]),
 	"slq_plan_profile_enable": (C.c_int, [_P, C.c_int]),
 	"slq_plan_profile_read": (C.c_int, [_P, C.POINTER(SlqProfile), C.c_int]),
 	"slq_quad_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, _P, _P]),

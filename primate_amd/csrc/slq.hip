@@ -915,12 +915,11 @@ static int launch_reorth_update(slq_plan *p, int j, int r, int istart) {
   return SLQ_OK;
 }
 
-extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_params, void *Y, int64_t ldy) {
-  if (!p || !Y) return fail(SLQ_EINVAL, "plan/Y is NULL");
+// Y = f(A) X on the device: result left in ring slot `deg` (panel layout)
+static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) {
   if (!p->keep_basis) return fail(SLQ_EINVAL, "plan was created without keep_basis");
-  if (!p->ran) return fail(SLQ_EINVAL, "slq_plan_fun_action: no completed run");
+  if (!p->ran) return fail(SLQ_EINVAL, "no completed run");
   if (fun_id < SLQ_FUN_IDENTITY || fun_id > SLQ_FUN_SOFTSIGN) return fail(SLQ_EINVAL, "Unknown function id %d.", fun_id);
-  if (ldy < p->n) return fail(SLQ_EINVAL, "ldy < n");
   HIP_TRY(hipSetDevice(p->ctx->device));
   hipStream_t st = p->ctx->stream;
   const int deg = p->deg;
@@ -930,22 +929,112 @@ extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_pa
   if (lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_fun_coeffs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipMemsetAsync(p->fail_d, 0, sizeof(int), st));
-  // gamma[t] = -g_t so that the update kernel's "w -= gamma W" accumulates +g_t W_t into a zeroed slot
+  // gamma row deg-1-t = -g_t: the update kernel's "w -= gamma W" then accumulates +g_t W_t into a
+  // zeroed slot while walking t = deg-1 .. 0
+  HIP_TRY(hipMemsetAsync(p->st.gamma, 0, (size_t)deg * p->bpad * 8, st));
   PROFILED(p, SLQ_K_QUADRATURE,
            (k_fun_coeffs<<<dim3(p->nprobes), dim3(64), lds, st>>>(p->st, fun_id, p0, p1, -1.0, 1, p->st.gamma, p->fail_d)));
-  // padding columns keep stale gamma: zero them (their W columns are zero anyway, but stay NaN-free)
-  if (p->bpad > p->nprobes)
-    for (int t = 0; t < deg; ++t)
-      HIP_TRY(hipMemsetAsync(p->st.gamma + (size_t)t * p->bpad + p->nprobes, 0, (size_t)(p->bpad - p->nprobes) * 8, st));
   // output accumulates in slot `deg` (the spare slot behind the basis; it held the last residual)
   HIP_TRY(hipMemsetAsync(slot_ptr(p, deg), 0, (size_t)p->slot_stride * p->esz, st));
-  // the update kernel walks t = (deg-1) - i for i = 0..deg-1: k_fun_coeffs stored g_t in row deg-1-t
   SLQ_TRY(launch_reorth_update(p, deg - 1, deg, 0));
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
-  SLQ_TRY(panel_to_host(p, deg, 0, p->nprobes, Y, ldy, nullptr));
+  HIP_TRY(hipStreamSynchronize(st));
   if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_params, void *Y, int64_t ldy) {
+  if (!p || !Y) return fail(SLQ_EINVAL, "plan/Y is NULL");
+  if (ldy < p->n) return fail(SLQ_EINVAL, "ldy < n");
+  SLQ_TRY(fun_action_device(p, fun_id, fun_params));
+  return panel_to_host(p, p->deg, 0, p->nprobes, Y, ldy, nullptr);
+}
+
+// ---- diagonal estimator state (device-resident) ----------------------------------------------------
+struct slq_diag {
+  slq_context *ctx;
+  int64_t n, count;
+  double *buf;  // numer | denom | msum, n doubles each
+};
+
+extern "C" int slq_diag_create(slq_context *ctx, int64_t n, slq_diag **out) {
+  if (!ctx || !out || n <= 0) return fail(SLQ_EINVAL, "bad arguments");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  slq_diag *d = new (std::nothrow) slq_diag();
+  if (!d) return fail(SLQ_ENOMEM, "host allocation failed");
+  d->ctx = ctx; d->n = n; d->count = 0; d->buf = nullptr;
+  hipError_t e = hipMalloc((void **)&d->buf, (size_t)3 * n * 8);
+  if (e == hipSuccess) e = hipMemsetAsync(d->buf, 0, (size_t)3 * n * 8, ctx->stream);
+  if (e != hipSuccess) { delete d; return fail(SLQ_ENOMEM, "diag accumulators: %s", hipGetErrorString(e)); }
+  *out = d;
+  return SLQ_OK;
+}
+
+extern "C" int slq_diag_destroy(slq_diag *d) {
+  if (!d) return SLQ_OK;
+  hipSetDevice(d->ctx->device);
+  if (d->buf) hipFree(d->buf);
+  delete d;
+  return SLQ_OK;
+}
+
+extern "C" int slq_diag_update(slq_diag *d, slq_plan *p, int fun_id, const double *fun_params) {
+  if (!d || !p) return fail(SLQ_EINVAL, "diag/plan is NULL");
+  if (d->n != p->n || d->ctx != p->ctx) return fail(SLQ_EINVAL, "diag accumulator does not match the plan");
+  SLQ_TRY(fun_action_device(p, fun_id, fun_params));
+  hipStream_t st = p->ctx->stream;
+  // coefB is free after a run: reuse it for the per-probe scale of the stored probes
+  k_probe_scale<<<dim3((p->bpad + 255) / 256), dim3(256), 0, st>>>(p->st, p->st.coefB);
+  const dim3 g((p->n + 63) / 64);
+  if (p->dtype == SLQ_F64)
+    k_diag_accumulate<double><<<g, dim3(64), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), (const double *)slot_ptr(p, p->deg),
+                                                      p->PW, p->nprobes, p->st.coefB, d->buf, d->buf + d->n, d->buf + 2 * d->n);
+  else
+    k_diag_accumulate<float><<<g, dim3(64), 0, st>>>(p->n, (const float *)slot_ptr(p, 0), (const float *)slot_ptr(p, p->deg),
+                                                     p->PW, p->nprobes, p->st.coefB, d->buf, d->buf + d->n, d->buf + 2 * d->n);
+  HIP_TRY(hipGetLastError());
+  d->count += p->nprobes;
+  return SLQ_OK;
+}
+
+extern "C" int slq_diag_get(slq_diag *d, double *numer, double *denom, double *running_mean, int64_t *count) {
+  if (!d) return fail(SLQ_EINVAL, "diag is NULL");
+  HIP_TRY(hipSetDevice(d->ctx->device));
+  hipStream_t st = d->ctx->stream;
+  if (numer) HIP_TRY(hipMemcpyAsync(numer, d->buf, (size_t)d->n * 8, hipMemcpyDeviceToHost, st));
+  if (denom) HIP_TRY(hipMemcpyAsync(denom, d->buf + d->n, (size_t)d->n * 8, hipMemcpyDeviceToHost, st));
+  if (running_mean) HIP_TRY(hipMemcpyAsync(running_mean, d->buf + 2 * d->n, (size_t)d->n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (running_mean && d->count > 0)
+    for (int64_t i = 0; i < d->n; ++i) running_mean[i] /= (double)d->count;
+  if (count) *count = d->count;
+  return SLQ_OK;
+}
+
+extern "C" int slq_fttr_batch(slq_context *ctx, int nb, int n, int k, const double *theta, const double *alpha,
+                              const double *beta, double *weights) {
+  if (!ctx || !theta || !alpha || !beta || !weights) return fail(SLQ_EINVAL, "NULL argument");
+  if (nb <= 0 || n <= 0 || k <= 0) return fail(SLQ_EINVAL, "bad sizes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *buf = nullptr;
+  const size_t nth = (size_t)nb * k, nab = (size_t)nb * n;
+  HIP_TRY(hipMalloc((void **)&buf, (2 * nth + 2 * nab) * 8));
+  double *dth = buf, *dw = buf + nth, *da = dw + nth, *db = da + nab;
+  hipError_t e = hipMemcpyAsync(dth, theta, nth * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(da, alpha, nab * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, beta, nab * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    k_fttr<<<dim3((unsigned)((nth + 127) / 128)), dim3(128), 0, st>>>(nb, n, k, dth, da, db, dw);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(weights, dw, nth * 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(buf);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "slq_fttr_batch: %s", hipGetErrorString(e));
   return SLQ_OK;
 }
 

@@ -1044,4 +1044,103 @@ __global__ void k_load_tridiag(StepState st, const double *__restrict__ d, const
   st.vnorm2[col] = 1.0;
 }
 
+
+// ---- diagonal estimator accumulation -------------------------------------------
+// Per probe p (in order): numer += u_p * v_p ; denom += v_p^2 ; msum += numer/denom, with
+// u_p = f(A) v_p — the loop body of the reference's diag() (src/primate/diagonal.py:74-79,86-91),
+// whose estimate is the running MEAN of the successive ratios numer/denom. Rows are independent;
+// the dependence is sequential over probes, so a wave takes 64 rows, stages 64 x 64 tiles of V and U
+// through LDS (coalesced loads, padded rows) and each lane scans its own row.
+// vscale[col] rescales the stored probe (sphere probes are kept as g with v = sqrt(n) g/||g||).
+template <typename F>
+__global__ __launch_bounds__(64) void k_diag_accumulate(int n, const F *__restrict__ Vp,
+                                                        const F *__restrict__ Up, int PW, int nprobes,
+                                                        const double *__restrict__ vscale,
+                                                        double *__restrict__ numer,
+                                                        double *__restrict__ denom,
+                                                        double *__restrict__ msum) {
+  __shared__ F tv[64][65], tu[64][65];
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * 64;
+  const int row = r0 + lane;
+  double nu = 0.0, de = 0.0, ms = 0.0;
+  if (row < n) {
+    nu = numer[row];
+    de = denom[row];
+    ms = msum[row];
+  }
+  for (int c0 = 0; c0 < nprobes; c0 += 64) {
+    const int col = c0 + lane;  // this lane loads column `col` of every row of the tile
+    const int panel = col / PW, pc = col % PW;
+    for (int r = 0; r < 64; ++r) {
+      const int rr = r0 + r;
+      F a = (F)0, b = (F)0;
+      if (rr < n && col < nprobes) {
+        const int64_t off = ((int64_t)panel * n + rr) * PW + pc;
+        a = Vp[off];
+        b = Up[off];
+      }
+      tv[r][lane] = a;
+      tu[r][lane] = b;
+    }
+    __syncthreads();
+    if (row < n) {
+      const int cmax = min(64, nprobes - c0);
+      for (int c = 0; c < cmax; ++c) {
+        const double v = (double)tv[lane][c] * vscale[c0 + c];
+        const double u = (double)tu[lane][c];
+        nu += u * v;
+        de += v * v;
+        ms += nu / de;
+      }
+    }
+    __syncthreads();
+  }
+  if (row < n) {
+    numer[row] = nu;
+    denom[row] = de;
+    msum[row] = ms;
+  }
+}
+
+// per-probe scale of the stored probe panel: sqrt(vnorm2)/nu_0 (1 unless sphere)
+__global__ void k_probe_scale(StepState st, double *__restrict__ vscale) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < st.bpad) {
+    const double nu0 = st.nu[col];
+    vscale[col] = nu0 > 0.0 ? sqrt(st.vnorm2[col]) / nu0 : 0.0;
+  }
+}
+
+// ---- FTTR weights ------------------------------------------------------------------
+// Forward three-term recurrence of the orthonormal polynomials of the Jacobi matrix (alpha, beta)
+// at each node: w_i = 1 / (mu_0 * sum_t p_t(theta_i)^2), mu_0 = sum |theta[:k]|, p_0 = mu_0^{-1/2}
+// (reference: src/primate/fttr.py:5-29, algorithm of Laudadio, Mastronardi & Van Dooren 2023).
+// One thread per (rule, node); theta/weights are [nb][k], alpha/beta [nb][n] (beta[:,0] unused).
+__global__ void k_fttr(int nb, int n, int k, const double *__restrict__ theta,
+                       const double *__restrict__ alpha, const double *__restrict__ beta,
+                       double *__restrict__ weights) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nb * k) return;
+  const int rule = idx / k;
+  const double *th = theta + (int64_t)rule * k;
+  const double *a = alpha + (int64_t)rule * n;
+  const double *b = beta + (int64_t)rule * n;
+  double mu0 = 0.0;
+  for (int i = 0; i < k; ++i) mu0 += fabs(th[i]);
+  const double x = th[idx % k];
+  double p0 = 1.0 / sqrt(mu0), ss = p0 * p0, p1 = 0.0;
+  if (n > 1) {
+    p1 = (x - a[0]) * p0 / b[1];
+    ss += p1 * p1;
+  }
+  for (int t = 2; t < n; ++t) {
+    const double pt = ((x - a[t - 1]) / b[t]) * p1 + (-b[t - 1] / b[t]) * p0;
+    ss += pt * pt;
+    p0 = p1;
+    p1 = pt;
+  }
+  weights[idx] = (1.0 / ss) / mu0;
+}
+
 }  // namespace slq

@@ -304,3 +304,51 @@ def quadrature_batch(d: np.ndarray, e: np.ndarray, fun=None, ctx: Optional[Conte
 	quad = np.zeros(nb)
 	check(_capi.lib().slq_quadrature_batch(ctx._h, nb, deg, ptr(d), ptr(e), fid, ptr(params), ptr(quad), ptr(nodes), ptr(weights)))
 	return (nodes, weights) if fun is None else (quad, nodes, weights)
+
+
+def fttr_batch(theta: np.ndarray, alpha: np.ndarray, beta: np.ndarray, k: Optional[int] = None, ctx: Optional[Context] = None) -> np.ndarray:
+	"""FTTR quadrature weights on the device (slq_fttr_batch); rows are independent rules."""
+	ctx = ctx or default_context()
+	theta = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+	alpha = np.ascontiguousarray(np.atleast_2d(alpha), dtype=np.float64)
+	beta = np.ascontiguousarray(np.atleast_2d(beta), dtype=np.float64)
+	nb, kk = theta.shape
+	k = kk if k is None else int(k)
+	assert alpha.shape == beta.shape and alpha.shape[0] == nb and k <= kk
+	w = np.zeros((nb, k))
+	check(_capi.lib().slq_fttr_batch(ctx._h, nb, alpha.shape[1], k, ptr(np.ascontiguousarray(theta[:, :k])), ptr(alpha), ptr(beta), ptr(w)))
+	return w
+
+
+class DiagAccumulator:
+	"""Device-resident numer / denom / running-mean accumulators of the diagonal estimator."""
+
+	def __init__(self, n: int, ctx: Optional[Context] = None):
+		self.ctx = ctx or default_context()
+		self.n = int(n)
+		h = C.c_void_p()
+		check(_capi.lib().slq_diag_create(self.ctx._h, self.n, C.byref(h)))
+		self._h = h
+
+	def update(self, plan: LanczosPlan, fun="identity", **fun_kwargs):
+		fid, params = fun_spec(fun, **fun_kwargs)
+		assert fid is not None, "the device diagonal path takes built-in function names"
+		check(_capi.lib().slq_diag_update(self._h, plan._h, fid, ptr(params)))
+
+	def get(self) -> tuple:
+		"""(numer, denom, running_mean, count)."""
+		nu, de, rm = np.zeros(self.n), np.zeros(self.n), np.zeros(self.n)
+		cnt = C.c_int64()
+		check(_capi.lib().slq_diag_get(self._h, ptr(nu), ptr(de), ptr(rm), C.byref(cnt)))
+		return nu, de, rm, cnt.value
+
+	def close(self):
+		if getattr(self, "_h", None):
+			_capi.lib().slq_diag_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:  # noqa: BLE001
+			pass

@@ -219,7 +219,30 @@ class ConfidenceCriterion(ConvergenceCriterion):
 		return f"Est: {_summary(est.estimate)} +/- {moe:.3f} ({self.confidence*100:.0f}% CI, #S:{ len(est) })"
 
 
-CRITERIA = {"count": CountCriterion, "tolerance": ToleranceCriterion, "confidence": ConfidenceCriterion}
+class KneeCriterion(ConvergenceCriterion):
+	"""Kneedle-style detection of the knee of the cumulative |change| of the running sample mean
+	(estimators.py:302-333). Needs an estimator created with record=True."""
+
+	def __init__(self, S: float = 1.0) -> None:
+		self.S = S
+
+	def __call__(self, est) -> bool:
+		if est.values is None or len(est.values) < 3:
+			return False
+		vals = np.array(est.values).ravel()
+		running = vals / np.arange(1, len(vals) + 1)
+		y = np.cumsum(np.abs(np.diff(running)))
+		y_norm = (y - y.min()) / (y.max() - y.min())
+		diff_curve = y_norm - np.linspace(0, 1, len(y))
+		peak = diff_curve[np.argmax(diff_curve)]
+		threshold = peak - (self.S / (len(y) - 1))
+		return bool(peak > threshold and diff_curve[-1] < threshold)
+
+	def message(self, est) -> str:
+		return f"Est: {_summary(est.estimate)} (#S:{ len(est) }, S={self.S:3f})"
+
+
+CRITERIA = {"count": CountCriterion, "tolerance": ToleranceCriterion, "confidence": ConfidenceCriterion, "knee": KneeCriterion}
 
 
 def convergence_criterion(criterion: Union[str, ConvergenceCriterion], **kwargs) -> ConvergenceCriterion:

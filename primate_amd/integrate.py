@@ -32,7 +32,12 @@ def quadrature(
 		theta, tau = engine.quadrature_batch(d[:deg][None, :], e[:deg][None, :])
 		theta, tau = theta[0].astype(d.dtype, copy=False), tau[0].astype(d.dtype, copy=False)
 	elif quad == "fttr":
-		raise NotImplementedError("quad='fttr' (SURVEY.md §8 row f4) is not built yet; use quad='gw'")
+		## nodes of the FULL Jacobi matrix, weights by the forward three-term recurrence over all of
+		## (d, e) for the first `deg` nodes (integrate.py:65-69, fttr.py:17-29), both on the device
+		theta, _ = engine.quadrature_batch(d[None, :], e[None, :])
+		theta = theta[0].astype(d.dtype, copy=False)
+		tau = np.zeros(len(theta), dtype=theta.dtype)
+		tau[:deg] = engine.fttr_batch(theta[None, :], d[None, :], e[None, :], k=deg)[0]
 	else:
 		raise ValueError(f"Invalid quadrature method '{quad}' supplied")
 	if nodes is not None and weights is not None:

@@ -1,0 +1,75 @@
+"""Estimator drivers on plain matrices (host path, no GPU): exact agreement with vectors captured
+from the reference's own hutchpp / xtrace / diag / xdiag / KneeCriterion ("pure" golden)."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def gd():
+	return np.load(ROOT / "tests" / "golden" / "slq_golden_drivers.npz")
+
+
+def test_hutchpp_matches_reference(gd):
+	from primate_amd.estimators import EstimatorResult
+	from primate_amd.trace import hutchpp
+
+	A = gd["A"]
+	assert hutchpp(A, m=30, seed=1234) == pytest.approx(float(gd["hutchpp_m30"]), rel=1e-13)
+	assert hutchpp(A, m=30, seed=1234, mode="full") == pytest.approx(float(gd["hutchpp_m30_full"]), rel=1e-13)
+	est, res = hutchpp(A, m=20, seed=5, full=True, pdf="normal")
+	assert isinstance(res, EstimatorResult) and res.nit == 2 * 22  # nb += nb % 3 (trace.py:151): 20 -> 22
+	assert est == pytest.approx(float(gd["hutchpp_m20_normal"]), rel=1e-13)
+	np.testing.assert_allclose(res.samples, gd["hutchpp_m20_samples"], rtol=1e-12)
+	assert abs(hutchpp(A, m=60, seed=1) - A.trace()) < 1e-8  # m = n: the sketch is exact
+
+
+def test_xtrace_matches_reference_including_its_quirks(gd):
+	from primate_amd.trace import xtrace
+
+	A = gd["A"]
+	for pdf in ["sphere", "rademacher", "normal"]:
+		for nb in [7, 20]:
+			assert xtrace(A, pdf=pdf, batch=nb, seed=1234) == pytest.approx(float(gd[f"xtrace_{pdf}_b{nb}"]), rel=1e-12)
+	est, info = xtrace(A, batch=16, seed=99, full=True)
+	assert est == pytest.approx(float(gd["xtrace_full_b16"]), rel=1e-12) and info.nit == A.shape[0]
+	assert abs(xtrace(A, batch=13, seed=3) - A.trace()) < 0.02 * A.trace()
+	## explicit probe budget (the reference cannot do this, trace.py:271-275)
+	ests = []
+	est, info = xtrace(A, batch=8, seed=3, count=24, full=True, callback=lambda r: ests.append(r.nit))
+	assert info.nit == 24 and ests == [8, 16, 24] and abs(est - A.trace()) < 0.15 * A.trace()
+
+
+def test_diag_and_xdiag_match_reference(gd):
+	from primate_amd.diagonal import diag, xdiag
+
+	A = gd["A"]
+	np.testing.assert_allclose(diag(A, converge="count", count=50, seed=1234), gd["diag_c50"], rtol=1e-13)
+	d, info = diag(A, converge="count", count=20, seed=7, full=True, pdf="normal")
+	np.testing.assert_allclose(d, gd["diag_c20_normal_full"], rtol=1e-13)
+	assert info.nit == 20 and info.criterion(info.estimator)
+	np.testing.assert_allclose(diag(A, converge="tolerance", atol=0.0, rtol=0.01, seed=3), gd["diag_tol"], rtol=1e-13)
+	np.testing.assert_allclose(xdiag(A, m=40, seed=1234), gd["xdiag_m40"], rtol=1e-12)
+	assert np.linalg.norm(xdiag(A, seed=1) - A.diagonal()) < 0.05 * np.linalg.norm(A.diagonal())
+
+
+def test_knee_criterion_and_update_trinv(gd):
+	from primate_amd.estimators import KneeCriterion, MeanEstimator, convergence_criterion
+	from primate_amd.linalg import update_trinv
+
+	kc, est, dec = convergence_criterion("knee", S=1.0), MeanEstimator(record=True), []
+	assert isinstance(kc, KneeCriterion)
+	for x in gd["knee_samples"]:
+		est.update(x)
+		dec.append(bool(kc(est)))
+	assert np.array_equal(dec, gd["knee_decisions"])
+	rng = np.random.default_rng(0)
+	R = np.triu(rng.standard_normal((6, 6))) + 3 * np.eye(6)
+	Rinv = np.zeros((0, 0))
+	for j in range(6):
+		Rinv = update_trinv(Rinv, R[: j + 1, j])
+	np.testing.assert_allclose(Rinv, np.linalg.inv(R), atol=1e-12)

@@ -170,3 +170,41 @@ def test_quadrature_api():
 	assert np.allclose(out_n, nodes) and np.allclose(out_w, weights)
 	with pytest.raises(ValueError):
 		quadrature(a, b, quad="nope")
+
+
+def test_drivers_over_matrix_function(golden):
+	"""diag / hutchpp / xtrace over a MatrixFunction: the reference's drivers ran over the oracle
+	("injected" golden, full reorth so the stale-ring quirk is absent: _matvec clears Q)."""
+	from pathlib import Path
+
+	from primate_amd.diagonal import diag
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutchpp, xtrace
+
+	gd = np.load(Path(__file__).resolve().parent / "golden" / "slq_golden_drivers.npz")
+	L = laplacian_2d(int(gd["lap_m"]))
+	M = MatrixFunction(L, fun="exp", deg=20, orth=20, t=-0.1)
+	## device accumulation path (count criterion) and the generic host loop give the reference's numbers
+	d_dev = diag(M, converge="count", count=30, seed=1234, batch=8)
+	np.testing.assert_allclose(d_dev, gd["mf_diag_c30"], rtol=1e-8)
+	d_host = diag(M, converge="count", count=30, seed=1234, record=True)
+	np.testing.assert_allclose(d_host, gd["mf_diag_c30"], rtol=1e-8)
+	d, info = diag(M, converge="count", count=30, seed=1234, full=True, batch=30)
+	np.testing.assert_allclose(info.info["numer"] / info.info["denom"], gd["mf_exact_diag"], atol=0.25)
+	assert hutchpp(M, m=24, seed=1234, mode="full") == pytest.approx(float(gd["mf_hutchpp_m24_full"]), rel=1e-8)
+	M0 = MatrixFunction(L, fun="exp", deg=20, orth=0, t=-0.1)
+	assert hutchpp(M0, m=24, seed=1234) == pytest.approx(float(gd["mf0_hutchpp_m24"]), rel=1e-8)
+	assert xtrace(M, batch=12, seed=1234) == pytest.approx(float(gd["mf_xtrace_b12"]), rel=1e-7)
+	assert xtrace(M, batch=16, seed=5, count=48) == pytest.approx(float(gd["mf_exact_trace"]), rel=3e-2)
+
+
+def test_fttr_quadrature_on_device():
+	from pathlib import Path
+
+	from primate_amd.integrate import quadrature
+
+	gd = np.load(Path(__file__).resolve().parent / "golden" / "slq_golden_drivers.npz")
+	a, b = gd["fttr_alpha"], gd["fttr_beta"]
+	th, w = quadrature(a, b, deg=15, quad="fttr")
+	np.testing.assert_allclose(th, gd["fttr_nodes"], atol=1e-13)
+	np.testing.assert_allclose(w, gd["fttr_weights"], rtol=1e-9)
