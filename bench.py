@@ -127,15 +127,23 @@ def main():
 
 	import torch
 
+	## Rehearsal knobs (one-GPU box): BENCH_BACKEND=gloo keeps the collective on the CPU and
+	## BENCH_DEVICE=0 puts every rank on one card. The driver's runs use neither: nccl (= RCCL over
+	## xGMI), one rank per GPU.
+	backend = os.environ.get("BENCH_BACKEND", "nccl")
+	if "BENCH_DEVICE" in os.environ:
+		local_rank = int(os.environ["BENCH_DEVICE"])
+	red_dev = "cuda" if backend == "nccl" else "cpu"
 	dist = None
+	torch.cuda.set_device(local_rank)
 	if world > 1:
 		import torch.distributed as dist
 
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		torch.cuda.set_device(local_rank)
-		dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-	else:
-		torch.cuda.set_device(local_rank)
+		if backend == "nccl":
+			dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+		else:
+			dist.init_process_group(backend, rank=rank, world_size=world)
 
 	from primate_amd.engine import Context, DeviceOperator, LanczosPlan
 
@@ -147,7 +155,6 @@ def main():
 	P, deg = args.probes, min(args.deg, n)
 	orth = deg if args.orth < 0 or args.orth > deg else args.orth
 	plan = LanczosPlan(op, P, deg, orth)
-	stats = torch.zeros(3, dtype=torch.float64, device="cuda")
 
 	def step(it: int):
 		## probe ids are global: rank r draws ids [ (it*world + r) * P, ... + P )
@@ -155,7 +162,7 @@ def main():
 		plan.run(1e-8)
 		q = plan.quadrature(args.fun)  # device QL + reduction; returns P doubles (synchronises)
 		if dist is not None:
-			st = torch.tensor([q.sum(), (q * q).sum(), float(len(q))], dtype=torch.float64, device="cuda")
+			st = torch.tensor([q.sum(), (q * q).sum(), float(len(q))], dtype=torch.float64, device=red_dev)
 			dist.all_reduce(st)  # RCCL over xGMI: the only collective on the path
 			return st
 		return q
@@ -179,7 +186,7 @@ def main():
 	barrier()
 	elapsed = time.perf_counter() - t0
 	if dist is not None:
-		tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+		tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 		elapsed = float(tmax.item())
 	prof = plan.profile_read(reset=True)

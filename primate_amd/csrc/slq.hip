@@ -93,7 +93,7 @@ struct slq_plan {
   StepState st;
   double *scal;         // one allocation behind all StepState arrays
   double *part;
-  int nblkA, nblkS;
+  int nblkA, nblkS, nblkU;  // grids: SpMM/alpha pass, streaming sweeps, fused dots/update passes
   double *quad_d, *nodes_d, *weights_d;
   int *fail_d;
   int rmax;
@@ -429,7 +429,7 @@ static int ring_slots(int deg, int orth, int keep_basis) {
   return std::max(orth + 1, 3);
 }
 
-static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nblkS) {
+static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nblkS, int *nblkU) {
   const int RPW = 64 / LPR;
   const int rows_per_block = kWaves * RPW;
   // Tunables: resident workgroups (kBlock threads) per CU, summed over the panels of a launch.
@@ -442,6 +442,11 @@ static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nbl
   int per_xcd = std::min(std::max(8, num_cus * per_cu_a / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   per_xcd = std::max(per_xcd, 1);
   *nblkA = 8 * per_xcd;
+  // fused dots/update passes hold ~100 VGPRs (2 workgroups resident per CU): a grid of exactly one
+  // or two resident waves of workgroups avoids a ragged tail (4/CU measured best; 5-7 lose 10-20 %)
+  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 4));
+  int per_xcd_u = std::min(std::max(8, num_cus * per_cu_u / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
+  *nblkU = 8 * std::max(per_xcd_u, 1);
   int s = std::min(std::max(1, num_cus * per_cu_s / NP), (n + rows_per_block - 1) / rows_per_block);
   *nblkS = std::max(s, 1);
 }
@@ -500,7 +505,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->S = ring_slots(deg, orth, p->keep_basis);
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
-  grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS);
+  grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
   memset(&p->acc, 0, sizeof(p->acc));
   memset(&p->st, 0, sizeof(p->st));
 
@@ -508,7 +513,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t bp = p->bpad;
   // alpha[deg+1], nu[deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
   const size_t nscal = ((size_t)(deg + 1) * 2 + 1 + 2 + 1 + (size_t)p->rmax) * bp;
-  const size_t npart = (size_t)kReorthChunk * std::max(p->nblkA, p->nblkS) * bp;
+  const size_t npart = (size_t)kReorthChunk * std::max(std::max(p->nblkA, p->nblkU), p->nblkS) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
@@ -709,7 +714,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   // alpha and nu[1..] start from zero (the reference's fresh np.zeros buffers, lanczos.py:101-102)
   HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
-  const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gF((bp + 63) / 64);
+  const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gU(p->nblkU, p->NP), gF((bp + 63) / 64);
   const slq_operator *op = p->op;
   const bool fused = env_int("SLQ_FUSED", 1) != 0;  // recompute-SpMM passes (default) vs store-and-revisit sweeps
   const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
@@ -724,7 +729,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS)                                                          \
   DISPATCH(p->dtype, p->LPR,                                                                         \
-           (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<gA, dim3(kBlock), LDS, st>>>(                           \
+           (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gA : gU), dim3(kBlock), LDS, st>>>(                           \
                p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, S,   \
                j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp)))
       PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, lds0); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, lds0); });
@@ -734,13 +739,13 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0); });
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
-                                    p->part, p->nblkA, j, 0, orth_tol));
+                                    p->part, p->nblkU, j, 0, orth_tol));
       }
       const size_t ldsU = lds0 + (size_t)r * p->PW * p->esz;
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
                { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU); });
 #undef CSR_PASS
-      nblk_last = p->nblkA;
+      nblk_last = p->nblkU;
     } else {
     if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
