@@ -221,9 +221,12 @@ def main():
 			traffic = rec.get(key, {}).get(dom, {}).get("hbm_bytes_per_launch")
 		except Exception:  # noqa: BLE001
 			traffic = None
+	## the rate this card actually sustains for the sweeps' access shape (SURVEY.md §8d asks for both)
+	measured = {m: round(ctx.measure_stream(m, nbytes=1 << 31, reps=5), 1) for m in ("read", "triad")}
 	roofline = {
 		"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
 		"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+		"measured_stream_GBps": measured, "frac_of_measured_triad": round(achieved / measured["triad"], 4),
 		"alg_bytes_per_launch": int(alg_bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
 	}  # fmt: skip
 	## whole-loop view: SURVEY §8(d) contract bytes per probe-matvec / wall time of the step
@@ -278,6 +281,18 @@ def main():
 			f"oracle/slq_oracle.c restating lanczos.h:43-149 + CSC SpMV + QL quadrature), {tc:.1f} s",
 			"s_per_probe": round(tc / cnt, 3), "estimate": float(np.mean(qc)),
 		}  # fmt: skip
+		## generous upper bound the reference does not have: all host cores, OpenMP over probes
+		ncore = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))  # the box's CPU share for one GPU
+		if ncore > 1 and not os.environ.get("BENCH_SKIP_CPU_PARALLEL"):
+			cntp = 2 * ncore
+			Xp = mk(cntp)
+			t = time.perf_counter()
+			oracle.quad_batch(A, Xp, deg, orth, fun=args.fun, fresh_q=True, nthreads=ncore)
+			tp = time.perf_counter() - t
+			line["cpu_baseline_all_cores"] = {
+				"value": round(cntp * deg / tp, 2), "unit": "probe-matvecs/s", "cores": ncore, "kind": "port",
+				"sample": f"{cntp} probes, OpenMP over probes ({ncore} threads), {tp:.1f} s; an upper bound: the reference is single-threaded",
+			}  # fmt: skip
 
 	if rank == 0:
 		print(json.dumps(line))

@@ -130,6 +130,9 @@ int slq_plan_query_bytes(int dtype, int64_t n, int nprobes, int deg, int orth, i
 
 /* Parity mode: host probes, column-major n x nprobes of the plan's dtype (ld >= n). */
 int slq_plan_set_probes(slq_plan *plan, const void *X, int64_t ldx);
+/* Same, probes already on the device (column-major n x nprobes, contiguous: ldx == n), on the
+ * context's stream: nothing crosses PCIe. */
+int slq_plan_set_probes_device(slq_plan *plan, const void *d_X, int64_t ldx);
 /* Throughput mode: counter-based Philox4x32-10 on the device; the stream of probe `i` depends
  * only on (seed, probe_offset + i), so results do not depend on how probes are sharded. */
 int slq_plan_generate_probes(slq_plan *plan, int pdf, uint64_t seed, uint64_t probe_offset);
@@ -162,6 +165,11 @@ int slq_plan_fun_action(slq_plan *plan, int fun_id, const double *fun_params, vo
 int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e,
                          int fun_id, const double *fun_params, double *quad, double *nodes,
                          double *weights);
+
+/* Device bandwidth probe with the access shape of the sweeps (16 B/lane, one contiguous window):
+ * mode 0 = two read streams, 1 = in-place triad (2 reads + 1 write), 2 = copy. Reports GB/s. Used by
+ * bench.py to quote the roofline fraction against the measured rate as well as the 8 TB/s spec. */
+int slq_measure_stream(slq_context *ctx, int mode, size_t bytes_per_stream, int reps, double *gbps);
 
 /* FTTR quadrature weights on the device (integrate.quadrature(..., quad="fttr"),
  * src/primate/integrate.py:65-69 -> src/primate/fttr.py:17-29): theta, weights are nb x k row-major;

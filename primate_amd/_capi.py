@@ -69,6 +69,8 @@ _SIGNATURES = {
 	"slq_plan_get_basis": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
 	"slq_plan_fun_action": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
 	"slq_quadrature_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+	"slq_measure_stream": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+	"slq_plan_set_probes_device": (C.c_int, [_P, _P, C.c_int64]),
 	"slq_fttr_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
 	"slq_diag_create": (C.c_int, [_P, C.c_int64, _PP]),
 	"slq_diag_destroy": (C.c_int, [_P]),
@@ -83,10 +85,36 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+def _preload_hip_runtime() -> None:
+	"""Keep ONE HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+	libamdhip64.so.7, the same as /opt/rocm's) and link to it by the unversioned file name; libslq
+	links to the soname. If libslq loads first, a later `import torch` pulls in a SECOND runtime and
+	torch then reports "No HIP GPUs are available". Loading torch's copy first (without importing
+	torch) makes libslq's NEEDED entry resolve to it, whichever order the user imports things in."""
+	import importlib.util
+	import sys
+
+	if "torch" in sys.modules:
+		return
+	try:
+		spec = importlib.util.find_spec("torch")
+	except (ImportError, ValueError):
+		spec = None
+	if spec is None or not spec.origin:
+		return
+	cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+	if cand.exists():
+		try:
+			C.CDLL(str(cand), mode=getattr(os, "RTLD_NOW", 2) | getattr(os, "RTLD_GLOBAL", 0x100))
+		except OSError:
+			pass
+
+
 def lib() -> C.CDLL:
 	"""Load primate_amd/_libslq.so (built by __graft_entry__.build()). Fails loudly if absent."""
 	global _lib
 	if _lib is None:
+		_preload_hip_runtime()
 		if not LIB_PATH.exists():
 			raise ImportError(
 				f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -105,6 +105,9 @@ struct slq_plan {
   slq_profile acc;
   std::vector<char> hbuf;  // host staging for callback operators
   size_t bytes;
+  hipGraphExec_t graph_exec;  // the k-step launch sequence captured once per (plan, rtol, variant)
+  double graph_rtol;
+  int graph_variant;
 };
 
 static int env_int(const char *name, int dflt) {
@@ -470,6 +473,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   hipStreamSynchronize(p->ctx->stream);
   for (auto &ev : p->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
   for (auto &ev : p->pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+  if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
   if (p->ring) hipFree(p->ring);
   if (p->T) hipFree(p->T);
   if (p->stage) hipFree(p->stage);
@@ -480,6 +484,8 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   delete p;
   return SLQ_OK;
 }
+
+static int set_kernel_attributes(slq_plan *p);
 
 extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, int deg, int orth,
                                int keep_basis, slq_plan **out) {
@@ -540,7 +546,34 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->st.deg = deg;
   p->nodes_d = p->quad_d + bp;
   p->weights_d = p->nodes_d + bp * (size_t)deg;
+  p->graph_exec = nullptr;
+  p->graph_rtol = 0.0;
+  p->graph_variant = -1;
+  {
+    const int rc = set_kernel_attributes(p);
+    if (rc != SLQ_OK) {
+      slq_plan_destroy(p);
+      return rc;
+    }
+  }
   *out = p;
+  return SLQ_OK;
+}
+
+// Kernels that may be launched with more than the default 64 KiB of dynamic LDS (gamma staging):
+// raise their limit once, outside any stream capture.
+template <typename F, int L> static hipError_t raise_lds_limits() {
+  hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
+}
+static int set_kernel_attributes(slq_plan *p) {
+  hipError_t ae = hipSuccess;
+  DISPATCH(p->dtype, p->LPR, (ae = raise_lds_limits<F, L>()));
+  HIP_TRY(ae);
   return SLQ_OK;
 }
 
@@ -701,10 +734,8 @@ static int quadrature_lanes(int deg) {
   return std::max(1, std::min(64, lanes));
 }
 
-extern "C" int slq_plan_run(slq_plan *p, double rtol) {
-  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
-  if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
-  HIP_TRY(hipSetDevice(p->ctx->device));
+// enqueue the deg-step launch sequence on the context stream (also run under stream capture)
+static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
   hipStream_t st = p->ctx->stream;
   const int bp = p->bpad, deg = p->deg, S = p->S;
   const double eps = p->dtype == SLQ_F64 ? std::numeric_limits<double>::epsilon()
@@ -716,8 +747,6 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
   const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gU(p->nblkU, p->NP), gF((bp + 63) / 64);
   const slq_operator *op = p->op;
-  const bool fused = env_int("SLQ_FUSED", 1) != 0;  // recompute-SpMM passes (default) vs store-and-revisit sweeps
-  const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
   for (int j = 0; j < deg; ++j) {
     const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
     const int first = (j == 0);
@@ -803,6 +832,50 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
              hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, nblk_last, j, residual_tol));
   }
   HIP_TRY(hipGetLastError());
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_run(slq_plan *p, double rtol) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const bool fused = env_int("SLQ_FUSED", 1) != 0;  // recompute-SpMM passes (default) vs store-and-revisit sweeps
+  const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
+  // The launch sequence of a run (7 launches per Lanczos step, ~210 for k = 30) depends only on
+  // the plan, so it is captured into a hipGraph once and replayed: launch-bound for small n,
+  // a few per cent for n = 1e6. Not used while per-kernel events are recorded, nor for host-callback
+  // operators (they synchronise with the host every step).
+  const bool graph_ok = env_int("SLQ_GRAPH", 1) != 0 && !p->prof && p->op->kind != OP_CALLBACK;
+  if (!graph_ok) {
+    SLQ_TRY(enqueue_run(p, rtol, fused, nt));
+  } else {
+    const int variant = (fused ? 1 : 0) | (nt ? 2 : 0);
+    if (!p->graph_exec || p->graph_rtol != rtol || p->graph_variant != variant) {
+      if (p->graph_exec) {
+        HIP_TRY(hipGraphExecDestroy(p->graph_exec));
+        p->graph_exec = nullptr;
+      }
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_run(p, rtol, fused, nt);
+      hipError_t ce = hipStreamEndCapture(st, &graph);
+      if (rc != SLQ_OK) {
+        if (graph) hipGraphDestroy(graph);
+        return rc;
+      }
+      if (ce != hipSuccess) return fail(SLQ_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+      ce = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (ce != hipSuccess) {
+        p->graph_exec = nullptr;
+        return fail(SLQ_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ce));
+      }
+      p->graph_rtol = rtol;
+      p->graph_variant = variant;
+    }
+    HIP_TRY(hipGraphLaunch(p->graph_exec, st));
+  }
   p->probes_ready = false;
   p->ran = true;
   return SLQ_OK;
@@ -904,13 +977,6 @@ static int launch_reorth_update(slq_plan *p, int j, int r, int istart) {
   for (int i0 = istart; i0 < r; i0 += kUpdChunk) {
     const int rc = std::min(kUpdChunk, r - i0);
     const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
-    if (lds > 48 * 1024) {
-      hipError_t ae = hipSuccess;
-      DISPATCH(p->dtype, p->LPR,
-               ae = hipFuncSetAttribute((const void *)k_reorth_update<F, L>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(ae);
-    }
     PROFILED(p, SLQ_K_REORTH_UPD,
              DISPATCH(p->dtype, p->LPR,
                       (k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(
@@ -1017,6 +1083,57 @@ extern "C" int slq_diag_get(slq_diag *d, double *numer, double *denom, double *r
     for (int64_t i = 0; i < d->n; ++i) running_mean[i] /= (double)d->count;
   if (count) *count = d->count;
   return SLQ_OK;
+}
+
+extern "C" int slq_measure_stream(slq_context *ctx, int mode, size_t bytes_per_stream, int reps, double *gbps) {
+  if (!ctx || !gbps || mode < 0 || mode > 2 || reps < 1 || bytes_per_stream < (1u << 20))
+    return fail(SLQ_EINVAL, "bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int64_t nvec = (int64_t)(bytes_per_stream / 16);
+  double *buf = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, (size_t)nvec * 32 + 64));
+  double *w = buf, *q = buf + nvec * 2, *sink = q + nvec * 2;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipMemsetAsync(buf, 0, (size_t)nvec * 32 + 64, st);
+  if (e == hipSuccess) e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  const int blocks = ctx->num_cus * 2;  // the launch shape of the streaming sweeps
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    for (int i = 0; i < 2; ++i) k_stream_probe<<<dim3(blocks), dim3(kBlock), 0, st>>>(w, q, nvec, mode, 1e-9, sink);
+    e = hipEventRecord(a, st);
+    for (int i = 0; i < reps; ++i) k_stream_probe<<<dim3(blocks), dim3(kBlock), 0, st>>>(w, q, nvec, mode, 1e-9, sink);
+    if (e == hipSuccess) e = hipEventRecord(b, st);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (e == hipSuccess) e = hipGetLastError();
+  }
+  if (a) hipEventDestroy(a);
+  if (b) hipEventDestroy(b);
+  hipFree(buf);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "slq_measure_stream: %s", hipGetErrorString(e));
+  const double streams = mode == 1 ? 3.0 : 2.0;
+  *gbps = streams * (double)nvec * 16.0 * reps / (ms * 1e-3) / 1e9;
+  return SLQ_OK;
+}
+
+extern "C" int slq_plan_set_probes_device(slq_plan *p, const void *d_X, int64_t ldx) {
+  if (!p || !d_X) return fail(SLQ_EINVAL, "plan/X is NULL");
+  if (ldx < p->n) return fail(SLQ_EINVAL, "ldx (%lld) < n (%d)", (long long)ldx, p->n);
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  if (ldx != p->n) return fail(SLQ_EINVAL, "device probes must be contiguous columns (ldx == n)");
+  if (p->nprobes < p->bpad) HIP_TRY(hipMemsetAsync(slot_ptr(p, 0), 0, (size_t)p->slot_stride * p->esz, st));
+  dim3 g((p->n + 63) / 64, (p->nprobes + 63) / 64);
+  PROFILED(p, SLQ_K_PROBES, {
+    if (p->dtype == SLQ_F64)
+      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)d_X, 0, p->nprobes, (double *)slot_ptr(p, 0), p->PW);
+    else
+      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)d_X, 0, p->nprobes, (float *)slot_ptr(p, 0), p->PW);
+  });
+  p->pdf_sphere = 0;
+  return init_from_probes(p, 0);
 }
 
 extern "C" int slq_fttr_batch(slq_context *ctx, int nb, int n, int k, const double *theta, const double *alpha,

@@ -1143,4 +1143,25 @@ __global__ void k_fttr(int nb, int n, int k, const double *__restrict__ theta,
   weights[idx] = (1.0 / ss) / mu0;
 }
 
+
+// ---- device bandwidth probe (bench.py: "fraction of the measured triad") ----------
+// mode 0: read-only dot of two streams (2R); 1: in-place triad w -= c*q (2R + 1W); 2: copy (1R + 1W).
+// 16 B per lane, one contiguous window swept by the whole grid — the access shape of the sweeps.
+__global__ __launch_bounds__(kBlock) void k_stream_probe(double *w, const double *q, int64_t nvec,
+                                                         int mode, double c, double *sink) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 *W = (d2 *)w;
+  const d2 *Q = (const d2 *)q;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  d2 acc = (d2)0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    d2 x;
+    if (mode == 0) x = W[i] * Q[i];
+    else if (mode == 1) { x = W[i] - c * Q[i]; W[i] = x; }
+    else { x = Q[i]; W[i] = x; }
+    acc += x;
+  }
+  if (acc[0] + acc[1] == 1.234567e-300) sink[0] = acc[0];
+}
+
 }  // namespace slq

@@ -54,6 +54,12 @@ class Context:
 	def synchronize(self):
 		check(_capi.lib().slq_context_synchronize(self._h))
 
+	def measure_stream(self, mode: str = "triad", nbytes: int = 1 << 31, reps: int = 10) -> float:
+		"""Measured device bandwidth in GB/s: mode 'read' (2 read streams), 'triad' (in place, 2R+1W) or 'copy'."""
+		g = C.c_double()
+		check(_capi.lib().slq_measure_stream(self._h, {"read": 0, "triad": 1, "copy": 2}[mode], int(nbytes), int(reps), C.byref(g)))
+		return g.value
+
 	def meminfo(self) -> tuple:
 		f, t = C.c_size_t(), C.c_size_t()
 		check(_capi.lib().slq_context_meminfo(self._h, C.byref(f), C.byref(t)))
@@ -183,6 +189,12 @@ class LanczosPlan:
 		assert X.shape == (self.op.shape[1], self.nprobes), f"probes must be {(self.op.shape[1], self.nprobes)}"
 		X = np.asfortranarray(X, dtype=self.op.dtype)
 		check(_capi.lib().slq_plan_set_probes(self._h, ptr(X), X.shape[0]))
+
+	def set_probes_device(self, dptr: int):
+		"""Probes already resident on this GPU: `dptr` is a device address of a contiguous column-major
+		n x nprobes array of the operator dtype (e.g. torch_tensor.data_ptr() of a (nprobes, n) C-ordered
+		tensor)."""
+		check(_capi.lib().slq_plan_set_probes_device(self._h, C.c_void_p(int(dptr)), self.op.shape[0]))
 
 	def generate_probes(self, pdf: str = "rademacher", seed: int = 0, probe_offset: int = 0):
 		assert pdf in _capi.PDF_IDS, f"Invalid distribution '{pdf}' supplied."

@@ -407,3 +407,22 @@ def test_abi_error_behaviour(eng):
 	h = C.c_void_p()
 	rc = _capi.lib().slq_csr_create(op.ctx._h, _capi.SLQ_F64, 2, 2, _capi.ptr(rowptr), _capi.ptr(colind), _capi.ptr(vals), C.byref(h))
 	assert rc == _capi.SLQ_EINVAL and b"rowptr" in _capi.lib().slq_last_error()
+
+
+def test_device_resident_probes_and_bandwidth_probe(eng, lap, golden):
+	"""slq_plan_set_probes_device: probes handed over as a device pointer (here a torch tensor's) give
+	bitwise the results of the host-pointer path; slq_measure_stream reports a sane HBM rate."""
+	import torch
+
+	L, op, V = lap
+	plan = eng.LanczosPlan(op, V.shape[1], 20, 3)
+	plan.set_probes(V)
+	plan.run()
+	q_host = plan.quadrature("log")
+	t = torch.from_numpy(np.ascontiguousarray(V.T)).cuda()  # (nprobes, n) C-order == column-major n x nprobes
+	torch.cuda.synchronize()
+	plan.set_probes_device(t.data_ptr())
+	plan.run()
+	assert np.array_equal(plan.quadrature("log"), q_host)
+	bw = op.ctx.measure_stream("triad", nbytes=1 << 28, reps=3)
+	assert 1000.0 < bw < 8000.0
