@@ -72,6 +72,8 @@ struct slq_operator {
   bool owns;
   slq_matvec_fn fn;
   void *user;
+  int32_t *perm_d;               // device: stored row i = caller row perm[i]; null if not reordered
+  std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
 };
 
 struct ProfEvent {
@@ -199,6 +201,82 @@ static int check_dtype(int dtype) {
   return SLQ_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// XCD-aware row reordering (speed only; results are permutation-invariant up to rounding)
+// ---------------------------------------------------------------------------------------------------
+// k_spmm_3term / k_csr_pass give XCD x the contiguous row range [x*n/8, (x+1)*n/8) and sweep it
+// with all of the XCD's waves in lock-step, so a gathered panel row stays useful only while the
+// sweep front is within the matrix bandwidth of it. With 1 KiB panel rows and a 4 MiB L2 the
+// natural order of a 1000 x 1000 grid (bandwidth 1000 -> 2 MiB of halo) no longer fits beside the
+// rows in flight: the alpha pass fetched 6.5 GB per launch against 4.2 GB algorithmic
+// (profiles/r01b_pmc_per_kernel.csv). Reverse Cuthill-McKee INSIDE each XCD's chunk shrinks the
+// bandwidth to the chunk's short dimension (125 for that grid; build/rcm_test in round 1). perm[new] = old.
+// MEASURED RESULT: slower, see slq_csr_create. The L2 behaviour of this kernel is not explained by
+// the reuse-distance model above (fewer resident workgroups also fetch MORE, not less).
+static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm) {
+  perm.resize((size_t)n);
+  const int64_t chunk = (n + 7) / 8;
+  std::vector<int32_t> deg((size_t)n), order, level, nbrs;
+  std::vector<char> seen((size_t)n, 0);
+  for (int x = 0; x < 8; ++x) {
+    const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    if (lo >= hi) break;
+    for (int64_t i = lo; i < hi; ++i) {
+      int d = 0;
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) d += (colind[p] >= lo && colind[p] < hi && colind[p] != i);
+      deg[(size_t)i] = d;
+    }
+    order.clear();
+    // candidates in increasing degree: starting points of the components
+    std::vector<int32_t> cand((size_t)(hi - lo));
+    for (int64_t i = lo; i < hi; ++i) cand[(size_t)(i - lo)] = (int32_t)i;
+    std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    auto bfs = [&](int32_t start, bool commit, int32_t *last_min) {
+      // breadth-first numbering with neighbours in increasing degree (Cuthill-McKee)
+      const size_t base = order.size();
+      order.push_back(start);
+      seen[(size_t)start] = 1;
+      size_t head = base, level_begin = base;
+      int32_t far = start;
+      while (head < order.size()) {
+        const size_t level_end = order.size();
+        level_begin = head;
+        for (; head < level_end; ++head) {
+          const int32_t u = order[head];
+          nbrs.clear();
+          for (int32_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+            const int32_t v = colind[p];
+            if (v >= lo && v < hi && !seen[(size_t)v]) {
+              seen[(size_t)v] = 1;
+              nbrs.push_back(v);
+            }
+          }
+          std::sort(nbrs.begin(), nbrs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b] || (deg[(size_t)a] == deg[(size_t)b] && a < b); });
+          order.insert(order.end(), nbrs.begin(), nbrs.end());
+        }
+      }
+      // min-degree node of the last level: a pseudo-peripheral candidate
+      far = order[level_begin];
+      for (size_t q = level_begin; q < order.size(); ++q)
+        if (deg[(size_t)order[q]] < deg[(size_t)far]) far = order[q];
+      if (last_min) *last_min = far;
+      if (!commit) {
+        for (size_t q = base; q < order.size(); ++q) seen[(size_t)order[q]] = 0;
+        order.resize(base);
+      }
+    };
+    for (int32_t c : cand) {
+      if (seen[(size_t)c]) continue;
+      int32_t far = c;
+      bfs(c, false, &far);      // one pseudo-peripheral refinement
+      bfs(far, true, nullptr);
+    }
+    // reverse within the chunk (RCM) and place
+    for (int64_t q = 0; q < hi - lo; ++q) perm[(size_t)(lo + q)] = order[(size_t)(hi - lo - 1 - q)];
+  }
+}
+
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
                               slq_operator **out) {
@@ -219,8 +297,47 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   HIP_TRY(hipSetDevice(ctx->device));
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr};
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr};
   const size_t es = esize(dtype);
+  // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
+  std::vector<int32_t> rp2, ci2;
+  std::vector<char> va2;
+  // OFF by default: on the 2-D grid of configs[1] it RAISED the alpha pass's fetch traffic from 6.5 to
+  // 8.9 GB per launch and its time from 0.97 to 1.20 ms — kept as an opt-in experiment
+  // (SLQ_REORDER=1: operators with n >= 65536; =2: all) so the permuted-row plumbing stays tested.
+  const int reorder_mode = env_int("SLQ_REORDER", 0);
+  if (reorder_mode != 0 && (n >= 65536 || reorder_mode == 2) && nnz > 0) {
+    op->perm_h = new (std::nothrow) std::vector<int32_t>();
+    if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+    std::vector<int32_t> &perm = *op->perm_h;
+    xcd_rcm_permutation(n, rowptr, colind, perm);
+    std::vector<int32_t> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+    rp2.resize((size_t)n + 1);
+    ci2.resize((size_t)nnz);
+    va2.resize((size_t)nnz * es);
+    rp2[0] = 0;
+    std::vector<std::pair<int32_t, int32_t>> rowbuf;
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t o = perm[(size_t)i];
+      rowbuf.clear();
+      for (int32_t q = rowptr[o]; q < rowptr[o + 1]; ++q) rowbuf.emplace_back(inv[(size_t)colind[q]], q);
+      std::sort(rowbuf.begin(), rowbuf.end());
+      int32_t w = rp2[(size_t)i];
+      for (auto &e2 : rowbuf) {
+        ci2[(size_t)w] = e2.first;
+        memcpy(va2.data() + (size_t)w * es, (const char *)vals + (size_t)e2.second * es, es);
+        ++w;
+      }
+      rp2[(size_t)i + 1] = w;
+    }
+    rowptr = rp2.data();
+    colind = ci2.data();
+    vals = va2.data();
+    hipError_t pe = hipMalloc((void **)&op->perm_d, (size_t)n * 4);
+    if (pe == hipSuccess) pe = hipMemcpyAsync(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
+  }
   hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&op->colind, std::max<size_t>((size_t)nnz * 4, 4));
   if (e == hipSuccess) e = hipMalloc(&op->vals, std::max<size_t>((size_t)nnz * es, 8));
@@ -248,7 +365,7 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, const_cast<int32_t *>(d_rowptr),
-                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr};
+                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr, nullptr, nullptr};
   *out = op;
   return SLQ_OK;
 }
@@ -262,7 +379,7 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr};
+  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr};
   const size_t es = esize(dtype);
   hipError_t e = hipMalloc(&op->vals, (size_t)n * n * es);
   if (e == hipSuccess)
@@ -286,7 +403,7 @@ extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_m
   if (!fn) return fail(SLQ_EINVAL, "Supplied object is missing 'matvec' attribute.");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user};
+  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr};
   *out = op;
   return SLQ_OK;
 }
@@ -299,6 +416,8 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
     if (op->colind) hipFree(op->colind);
     if (op->vals) hipFree(op->vals);
   }
+  if (op->perm_d) hipFree(op->perm_d);
+  delete op->perm_h;
   delete op;
   return SLQ_OK;
 }
@@ -635,9 +754,9 @@ extern "C" int slq_plan_set_probes(slq_plan *p, const void *X, int64_t ldx) {
     dim3 g((p->n + 63) / 64, (nc + 63) / 64);
     PROFILED(p, SLQ_K_PROBES, {
       if (p->dtype == SLQ_F64)
-        hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)slot_ptr(p, 0), p->PW);
+        hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)slot_ptr(p, 0), p->PW, p->op->perm_d);
       else
-        hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)slot_ptr(p, 0), p->PW);
+        hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)slot_ptr(p, 0), p->PW, p->op->perm_d);
     });
     HIP_TRY(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
   }
@@ -672,9 +791,9 @@ static int panel_to_host(slq_plan *p, int slot, int c0, int nc, void *X, int64_t
     const int m = std::min(cc, nc - o);
     dim3 g((p->n + 63) / 64, (m + 63) / 64);
     if (p->dtype == SLQ_F64)
-      hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, slot), c0 + o, m, (double *)p->stage, p->PW, d_scale);
+      hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, slot), c0 + o, m, (double *)p->stage, p->PW, d_scale, p->op->perm_d);
     else
-      hipLaunchKernelGGL(k_panel_to_cols<float>, g, dim3(256), 0, st, p->n, (const float *)slot_ptr(p, slot), c0 + o, m, (float *)p->stage, p->PW, d_scale);
+      hipLaunchKernelGGL(k_panel_to_cols<float>, g, dim3(256), 0, st, p->n, (const float *)slot_ptr(p, slot), c0 + o, m, (float *)p->stage, p->PW, d_scale, p->op->perm_d);
     HIP_TRY(hipMemcpy2DAsync((char *)X + (size_t)o * (size_t)ldx * p->esz, (size_t)ldx * p->esz, p->stage,
                              (size_t)p->n * p->esz, (size_t)p->n * p->esz, (size_t)m, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -717,9 +836,9 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
     HIP_TRY(hipMemcpyAsync(p->stage, hy + colb * c0, colb * nc, hipMemcpyHostToDevice, st));
     dim3 g((p->n + 63) / 64, (nc + 63) / 64);
     if (p->dtype == SLQ_F64)
-      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)p->T, p->PW);
+      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)p->stage, c0, nc, (double *)p->T, p->PW, p->op->perm_d);
     else
-      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)p->T, p->PW);
+      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)p->T, p->PW, p->op->perm_d);
     HIP_TRY(hipStreamSynchronize(st));
   }
   return SLQ_OK;
@@ -1027,7 +1146,8 @@ extern "C" int slq_plan_fun_action(slq_plan *p, int fun_id, const double *fun_pa
 struct slq_diag {
   slq_context *ctx;
   int64_t n, count;
-  double *buf;  // numer | denom | msum, n doubles each
+  double *buf;  // numer | denom | msum, n doubles each (in the operator's stored row order)
+  const slq_operator *op;
 };
 
 extern "C" int slq_diag_create(slq_context *ctx, int64_t n, slq_diag **out) {
@@ -1036,7 +1156,7 @@ extern "C" int slq_diag_create(slq_context *ctx, int64_t n, slq_diag **out) {
   HIP_TRY(hipSetDevice(ctx->device));
   slq_diag *d = new (std::nothrow) slq_diag();
   if (!d) return fail(SLQ_ENOMEM, "host allocation failed");
-  d->ctx = ctx; d->n = n; d->count = 0; d->buf = nullptr;
+  d->ctx = ctx; d->n = n; d->count = 0; d->buf = nullptr; d->op = nullptr;
   hipError_t e = hipMalloc((void **)&d->buf, (size_t)3 * n * 8);
   if (e == hipSuccess) e = hipMemsetAsync(d->buf, 0, (size_t)3 * n * 8, ctx->stream);
   if (e != hipSuccess) { delete d; return fail(SLQ_ENOMEM, "diag accumulators: %s", hipGetErrorString(e)); }
@@ -1055,6 +1175,8 @@ extern "C" int slq_diag_destroy(slq_diag *d) {
 extern "C" int slq_diag_update(slq_diag *d, slq_plan *p, int fun_id, const double *fun_params) {
   if (!d || !p) return fail(SLQ_EINVAL, "diag/plan is NULL");
   if (d->n != p->n || d->ctx != p->ctx) return fail(SLQ_EINVAL, "diag accumulator does not match the plan");
+  if (d->op && d->op != p->op) return fail(SLQ_EINVAL, "diag accumulator was started with another operator");
+  d->op = p->op;
   SLQ_TRY(fun_action_device(p, fun_id, fun_params));
   hipStream_t st = p->ctx->stream;
   // coefB is free after a run: reuse it for the per-probe scale of the stored probes
@@ -1081,6 +1203,15 @@ extern "C" int slq_diag_get(slq_diag *d, double *numer, double *denom, double *r
   HIP_TRY(hipStreamSynchronize(st));
   if (running_mean && d->count > 0)
     for (int64_t i = 0; i < d->n; ++i) running_mean[i] /= (double)d->count;
+  if (d->op && d->op->perm_h) {  // stored row i is caller row perm[i]
+    const std::vector<int32_t> &perm = *d->op->perm_h;
+    std::vector<double> tmp((size_t)d->n);
+    for (double *arr : {numer, denom, running_mean}) {
+      if (!arr) continue;
+      for (int64_t i = 0; i < d->n; ++i) tmp[(size_t)perm[(size_t)i]] = arr[i];
+      memcpy(arr, tmp.data(), (size_t)d->n * 8);
+    }
+  }
   if (count) *count = d->count;
   return SLQ_OK;
 }
@@ -1128,9 +1259,9 @@ extern "C" int slq_plan_set_probes_device(slq_plan *p, const void *d_X, int64_t 
   dim3 g((p->n + 63) / 64, (p->nprobes + 63) / 64);
   PROFILED(p, SLQ_K_PROBES, {
     if (p->dtype == SLQ_F64)
-      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)d_X, 0, p->nprobes, (double *)slot_ptr(p, 0), p->PW);
+      hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)d_X, 0, p->nprobes, (double *)slot_ptr(p, 0), p->PW, p->op->perm_d);
     else
-      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)d_X, 0, p->nprobes, (float *)slot_ptr(p, 0), p->PW);
+      hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)d_X, 0, p->nprobes, (float *)slot_ptr(p, 0), p->PW, p->op->perm_d);
   });
   p->pdf_sphere = 0;
   return init_from_probes(p, 0);

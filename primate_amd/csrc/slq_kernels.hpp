@@ -664,15 +664,18 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_gamma(StepState st, const d
 // ---- probes ------------------------------------------------------------------------------------------
 // Column-major host-order staging chunk Xs (n x nc, ld = n, columns c0..c0+nc of the batch)
 // -> panel layout slot. 64x64 tiles through LDS so both sides are coalesced.
+// perm (optional): panel row i holds caller row perm[i] (operator stored in a permuted row order).
 template <typename F>
 __global__ __launch_bounds__(256) void k_cols_to_panel(int n, const F *__restrict__ Xs, int c0,
-                                                       int nc, F *W, int PW) {
+                                                       int nc, F *W, int PW,
+                                                       const int32_t *__restrict__ perm) {
   __shared__ F tile[64][65];
   const int r0 = blockIdx.x * 64, cb = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int srow = (r0 + tx < n) ? (perm ? perm[r0 + tx] : r0 + tx) : 0;
   for (int c = ty; c < 64; c += 4) {
     const int col = cb + c, row = r0 + tx;
-    tile[c][tx] = (col < nc && row < n) ? Xs[(int64_t)col * n + row] : (F)0;
+    tile[c][tx] = (col < nc && row < n) ? Xs[(int64_t)col * n + srow] : (F)0;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
@@ -688,7 +691,8 @@ __global__ __launch_bounds__(256) void k_cols_to_panel(int n, const F *__restric
 template <typename F>
 __global__ __launch_bounds__(256) void k_panel_to_cols(int n, const F *__restrict__ W, int c0,
                                                        int nc, F *Xs, int PW,
-                                                       const double *__restrict__ scale) {
+                                                       const double *__restrict__ scale,
+                                                       const int32_t *__restrict__ perm) {
   __shared__ F tile[64][65];
   const int r0 = blockIdx.x * 64, cb = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -703,9 +707,10 @@ __global__ __launch_bounds__(256) void k_panel_to_cols(int n, const F *__restric
     tile[r][tx] = x;
   }
   __syncthreads();
+  const int drow = (r0 + tx < n) ? (perm ? perm[r0 + tx] : r0 + tx) : 0;
   for (int c = ty; c < 64; c += 4) {
     const int col = cb + c, row = r0 + tx;
-    if (col < nc && row < n) Xs[(int64_t)col * n + row] = tile[tx][c];
+    if (col < nc && row < n) Xs[(int64_t)col * n + drow] = tile[tx][c];
   }
 }
 

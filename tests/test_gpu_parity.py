@@ -426,3 +426,30 @@ def test_device_resident_probes_and_bandwidth_probe(eng, lap, golden):
 	assert np.array_equal(plan.quadrature("log"), q_host)
 	bw = op.ctx.measure_stream("triad", nbytes=1 << 28, reps=3)
 	assert 1000.0 < bw < 8000.0
+
+
+def test_opt_in_row_reordering_is_transparent(oracle, eng, monkeypatch):
+	"""SLQ_REORDER=2 stores P A P^T (RCM inside each XCD chunk): every host-visible array (probes,
+	basis, f(A)v, diag) must come back in the caller's row order and the values agree to rounding."""
+	A = random_spd_graph(777, 5.0, seed=21)
+	rng = np.random.default_rng(4)
+	X = np.asfortranarray(rng.standard_normal((777, 9)))
+	ref = oracle.quad_batch(A, X, 20, 3, fun="log", fresh_q=True, prefer="csr")
+	monkeypatch.setenv("SLQ_REORDER", "2")
+	op = eng.DeviceOperator(A)
+	monkeypatch.delenv("SLQ_REORDER")
+	np.testing.assert_allclose(eng.quad_batch(op, X, 20, 3, fun="log"), ref, rtol=1e-10)
+	np.testing.assert_allclose(op.matmat(X), A @ X, rtol=1e-12, atol=1e-12)
+	plan = eng.LanczosPlan(op, 9, 20, 20, keep_basis=True)
+	plan.set_probes(X)
+	assert np.array_equal(plan.get_probes(), X)
+	plan.run()
+	Q = plan.basis(2)
+	np.testing.assert_allclose(Q[:, 0], X[:, 2] / np.linalg.norm(X[:, 2]), rtol=1e-13)
+	np.testing.assert_allclose(Q.T @ Q, np.eye(20), atol=1e-10)
+	np.testing.assert_allclose(plan.fun_action("identity"), A @ X, rtol=1e-9, atol=1e-9)
+	acc = eng.DiagAccumulator(777, ctx=op.ctx)
+	acc.update(plan, "identity")
+	numer, denom, _, cnt = acc.get()
+	np.testing.assert_allclose(numer, np.sum((A @ X) * X, axis=1), rtol=1e-9, atol=1e-9)
+	np.testing.assert_allclose(denom, np.sum(X * X, axis=1), rtol=1e-12)
