@@ -74,6 +74,7 @@ struct slq_operator {
   void *user;
   int32_t *perm_d;               // device: stored row i = caller row perm[i]; null if not reordered
   std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
+  RowTiles tiles;                // LDS row tiles for the wide-panel fused passes (tile_ptr == null: none)
 };
 
 struct ProfEvent {
@@ -95,7 +96,7 @@ struct slq_plan {
   StepState st;
   double *scal;         // one allocation behind all StepState arrays
   double *part;
-  int nblkA, nblkS, nblkU;  // grids: SpMM/alpha pass, streaming sweeps, fused dots/update passes
+  int nblkA, nblkS, nblkU, nblkT;  // grids: SpMM/alpha pass, streaming sweeps, fused dots/update passes, tiled passes
   double *quad_d, *nodes_d, *weights_d;
   int *fail_d;
   int rmax;
@@ -277,6 +278,57 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
   }
 }
 
+
+// Row tiles for k_csr_pass_tiled: per tile of TR consecutive rows, the sorted list of distinct
+// columns (plus the rows themselves) and, per nonzero, its position in that list. Built once on the
+// host from the (possibly reordered) CSR arrays. Returns false if even TR = 8 needs more than
+// `cap` panel rows of LDS per tile (irregular / random sparsity: no reuse to exploit, generic path).
+static bool build_row_tiles(int64_t n, const int32_t *rowptr, const int32_t *colind, int cap, int *TR_out,
+                            std::vector<int32_t> &tile_ptr, std::vector<int32_t> &tile_cols,
+                            std::vector<uint16_t> &lidx, std::vector<uint16_t> &self_idx, int *tiles_per_xcd,
+                            int *max_cols) {
+  const int forced = env_int("SLQ_TILE_ROWS", 0);
+  for (int TR : {16, 8}) {
+    if (forced && TR != forced) continue;
+    const int64_t ntiles_real = (n + TR - 1) / TR;
+    const int tpx = (int)((ntiles_real + 7) / 8);
+    const int64_t ntiles = (int64_t)tpx * 8;
+    tile_ptr.assign((size_t)ntiles + 1, 0);
+    tile_cols.clear();
+    lidx.assign((size_t)rowptr[n], 0);
+    self_idx.assign((size_t)n, 0);
+    std::vector<int32_t> u;
+    int mx = 0;
+    bool ok = true;
+    for (int64_t t = 0; t < ntiles && ok; ++t) {
+      const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
+      u.clear();
+      for (int64_t r = r0; r < r1; ++r) {
+        u.push_back((int32_t)r);
+        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) u.push_back(colind[p]);
+      }
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      if ((int)u.size() > cap) { ok = false; break; }
+      mx = std::max(mx, (int)u.size());
+      for (int64_t r = r0; r < r1; ++r) {
+        self_idx[(size_t)r] = (uint16_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin());
+        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
+          lidx[(size_t)p] = (uint16_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin());
+      }
+      tile_cols.insert(tile_cols.end(), u.begin(), u.end());
+      tile_ptr[(size_t)t + 1] = (int32_t)tile_cols.size();
+    }
+    if (ok) {
+      *TR_out = TR;
+      *tiles_per_xcd = tpx;
+      *max_cols = mx;
+      return true;
+    }
+  }
+  return false;
+}
+
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
                               slq_operator **out) {
@@ -297,7 +349,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   HIP_TRY(hipSetDevice(ctx->device));
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr};
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   const size_t es = esize(dtype);
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
   std::vector<int32_t> rp2, ci2;
@@ -349,6 +401,34 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     slq_operator_destroy(op);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
   }
+  // LDS row tiles (wide-panel fused passes). EXPERIMENTAL, off by default: the barrier-coupled
+  // load -> compute structure of k_csr_pass_tiled exposes one HBM latency per tile and ran 2x SLOWER
+  // than the generic passes on configs[1] (2.1 vs 0.98 ms for the alpha pass). It is
+  // the scaffold for a double-buffered LDS-DMA version; SLQ_TILES=1 enables it.
+  if (env_int("SLQ_TILES", 0) != 0 && nnz > 0) {
+    std::vector<int32_t> tp, tc;
+    std::vector<uint16_t> li, si;
+    int TR = 0, tpx = 0, mx = 0;
+    const int cap = env_int("SLQ_TILE_CAP", 64);  // panel rows (1 KiB each) of LDS per tile: 2 workgroups per CU
+    if (build_row_tiles(n, rowptr, colind, cap, &TR, tp, tc, li, si, &tpx, &mx)) {
+      int32_t *d_tp = nullptr, *d_tc = nullptr;
+      uint16_t *d_li = nullptr, *d_si = nullptr;
+      hipError_t te = hipMalloc((void **)&d_tp, tp.size() * 4);
+      if (te == hipSuccess) te = hipMalloc((void **)&d_tc, std::max<size_t>(tc.size(), 1) * 4);
+      if (te == hipSuccess) te = hipMalloc((void **)&d_li, std::max<size_t>(li.size(), 1) * 2);
+      if (te == hipSuccess) te = hipMalloc((void **)&d_si, si.size() * 2);
+      if (te == hipSuccess) te = hipMemcpyAsync(d_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+      if (te == hipSuccess) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+      if (te == hipSuccess) te = hipMemcpyAsync(d_li, li.data(), li.size() * 2, hipMemcpyHostToDevice, ctx->stream);
+      if (te == hipSuccess) te = hipMemcpyAsync(d_si, si.data(), si.size() * 2, hipMemcpyHostToDevice, ctx->stream);
+      if (te == hipSuccess) te = hipStreamSynchronize(ctx->stream);
+      op->tiles = RowTiles{d_tp, d_tc, d_li, d_si, TR, mx, tpx};
+      if (te != hipSuccess) {
+        slq_operator_destroy(op);
+        return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "row-tile upload: %s", hipGetErrorString(te));
+      }
+    }
+  }
   *out = op;
   return SLQ_OK;
 }
@@ -365,7 +445,7 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, const_cast<int32_t *>(d_rowptr),
-                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr, nullptr, nullptr};
+                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   *out = op;
   return SLQ_OK;
 }
@@ -379,7 +459,7 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
   HIP_TRY(hipSetDevice(ctx->device));
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr};
+  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   const size_t es = esize(dtype);
   hipError_t e = hipMalloc(&op->vals, (size_t)n * n * es);
   if (e == hipSuccess)
@@ -403,7 +483,7 @@ extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_m
   if (!fn) return fail(SLQ_EINVAL, "Supplied object is missing 'matvec' attribute.");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr};
+  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr, RowTiles{}};
   *out = op;
   return SLQ_OK;
 }
@@ -418,6 +498,12 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   }
   if (op->perm_d) hipFree(op->perm_d);
   delete op->perm_h;
+  if (op->tiles.tile_ptr) {
+    hipFree((void *)op->tiles.tile_ptr);
+    hipFree((void *)op->tiles.tile_cols);
+    hipFree((void *)op->tiles.lidx);
+    hipFree((void *)op->tiles.self_idx);
+  }
   delete op;
   return SLQ_OK;
 }
@@ -557,7 +643,7 @@ static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nbl
   // Tunables: resident workgroups (kBlock threads) per CU, summed over the panels of a launch.
   // Defaults from the MI355X sweeps: in-place read-modify-write sweeps peak at
   // ~2 workgroups per CU (more concurrent writers lose 5-10 %); the SpMM likes 4-8.
-  const int per_cu_a = std::max(1, env_int("SLQ_BLOCKS_PER_CU_SPMM", env_int("SLQ_BLOCKS_PER_CU", 8)));
+  const int per_cu_a = std::max(1, env_int("SLQ_BLOCKS_PER_CU_SPMM", env_int("SLQ_BLOCKS_PER_CU", 4)));
   const int per_cu_s = std::max(1, env_int("SLQ_BLOCKS_PER_CU_STREAM", env_int("SLQ_BLOCKS_PER_CU", 2)));
   // sweep A: a multiple of 8 blocks (XCD-aware chunking), no more than the rows can feed
   const int chunk = (n + 7) / 8;
@@ -631,6 +717,13 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
+  {
+    // tiled passes: 2 workgroups per CU resident (LDS-limited), one panel at a time
+    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", 2));
+    int per_xcd_t = std::max(1, ctx->num_cus * per_cu_t / 8);
+    if (op->tiles.tile_ptr) per_xcd_t = std::min(per_xcd_t, std::max(1, op->tiles.tiles_per_xcd));
+    p->nblkT = 8 * per_xcd_t;
+  }
   memset(&p->acc, 0, sizeof(p->acc));
   memset(&p->st, 0, sizeof(p->st));
 
@@ -638,7 +731,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t bp = p->bpad;
   // alpha[deg+1], nu[deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
   const size_t nscal = ((size_t)(deg + 1) * 2 + 1 + 2 + 1 + (size_t)p->rmax) * bp;
-  const size_t npart = (size_t)kReorthChunk * std::max(std::max(p->nblkA, p->nblkU), p->nblkS) * bp;
+  const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(p->nblkA, p->nblkU), p->nblkS), p->nblkT) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
@@ -687,6 +780,15 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
     e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 1, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kFusedMaxR>,
+                             (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kFusedMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kFusedMaxR>,
+                             (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kFusedMaxR>};
+  for (const void *fn : tiled_fns)
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
 static int set_kernel_attributes(slq_plan *p) {
@@ -865,6 +967,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
   HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
   const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gU(p->nblkU, p->NP), gF((bp + 63) / 64);
+  const dim3 gT(p->nblkT, p->NP);
   const slq_operator *op = p->op;
   for (int j = 0; j < deg; ++j) {
     const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
@@ -875,25 +978,46 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
+      const int fused_alpha_pad = 65536;
+      // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
+      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0;
+      const size_t lds_tile = tiled ? (size_t)op->tiles.max_cols * p->PW * p->esz : 0;
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS)                                                          \
-  DISPATCH(p->dtype, p->LPR,                                                                         \
-           (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gA : gU), dim3(kBlock), LDS, st>>>(                           \
-               p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, S,   \
-               j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp)))
-      PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, lds0); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, lds0); });
+  do {                                                                                               \
+    if (tiled) {                                                                                     \
+      if (p->dtype == SLQ_F64)                                                                       \
+        k_csr_pass_tiled<double, PASS, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+            p->n, op->rowptr, (const double *)op->vals, op->tiles, (double *)p->ring, p->slot_stride, S, \
+            j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
+      else                                                                                           \
+        k_csr_pass_tiled<float, PASS, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+            p->n, op->rowptr, (const float *)op->vals, op->tiles, (float *)p->ring, p->slot_stride, S, \
+            j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
+    } else {                                                                                         \
+      DISPATCH(p->dtype, p->LPR,                                                                     \
+               (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gA : gU), dim3(kBlock), LDS, st>>>( \
+                   p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, S, \
+                   j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp))); \
+    }                                                                                                \
+  } while (0)
+      // alpha pass: its 58 VGPRs would admit 4 workgroups per CU; 2 resident ones (64 KiB of LDS padding)
+      // keep the rows in flight per XCD at 512 and the panels strictly one after the other, which
+      // measured 4-5 % faster than 4 per CU (0.92 vs 0.96 ms) and fetches less
+      const size_t ldsA = lds0 + (size_t)env_int("SLQ_ALPHA_LDS_PAD", fused_alpha_pad);
+      PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA); });
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkA, j));
       if (r > 0) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0); });
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
-                                    p->part, p->nblkU, j, 0, orth_tol));
+                                    p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
       }
       const size_t ldsU = lds0 + (size_t)r * p->PW * p->esz;
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
                { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU); });
 #undef CSR_PASS
-      nblk_last = p->nblkU;
+      nblk_last = tiled ? p->nblkT : p->nblkU;
     } else {
     if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy

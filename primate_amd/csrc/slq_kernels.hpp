@@ -297,6 +297,139 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   }
 }
 
+// ---- tiled fused passes: gathered panel rows staged ONCE per row tile through LDS ----------------
+// The generic passes above re-gather every nonzero's panel row from L2: for the 5-point stencil
+// 7 KiB reach the CU per output row, 14 GB per launch, and the passes sit at the ~17 TB/s the
+// XCD L2s can deliver to the CUs for 1-KiB row gathers (MI355X_MICROARCH.md 'Indexed rows'), not
+// at the HBM rate. Here a workgroup takes TR consecutive rows, loads each DISTINCT column's panel
+// row once into an LDS tile (the column list of the tile is precomputed on the host when the
+// operator is created: slq.hip:build_row_tiles), and all nonzeros read LDS. For the stencil that is
+// (3 TR + 2)/TR + 1 = 4.1 KiB per row instead of 7. `lidx` holds, per nonzero, the position of its
+// column in the tile's list (uint16), replacing the 4-byte column index in the CSR stream.
+struct RowTiles {
+  const int32_t *tile_ptr;   // [ntiles + 1] offsets into tile_cols
+  const int32_t *tile_cols;  // distinct global columns of each tile, ascending
+  const uint16_t *lidx;      // [nnz] local column position of every nonzero
+  const uint16_t *self_idx;  // [n] local position of the row's own index (always in the list)
+  int rows_per_tile;         // TR
+  int max_cols;              // largest tile list (LDS sizing)
+  int tiles_per_xcd;         // tiles in one XCD's chunk (chunk = tiles_per_xcd * TR rows)
+};
+
+template <typename F, int PASS, int LP, int SP, int DCH>
+__global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
+    int n, const int32_t *__restrict__ rowptr, const F *__restrict__ vals, RowTiles rt, F *ring,
+    int64_t slot_stride, int S, int j, int i0, int rc, const double *__restrict__ coefA,
+    const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
+    int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int LPR = 64;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double *red = (double *)lds_raw;                                  // kWaves*64*V doubles
+  F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);        // PASS_UPDATE: rc * PW
+  F *tile = gl + (PASS == PASS_UPDATE ? rc * PW : 0);               // max_cols * PW
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + lane * V;
+  const int first = (j == 0);
+  const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
+  F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *U0 = ring + poff;
+  const int colbase = panel * PW + lane * V;
+  VF sc, cp, cb = (VF)(F)0;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    sc[v] = (F)coefA[colbase + v];
+    cp[v] = (F)coefA[bpad + colbase + v];
+    if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
+  }
+  if (PASS == PASS_UPDATE) {
+    for (int t = threadIdx.x; t < rc * PW; t += kBlock)
+      gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+  }
+  const int TR = rt.rows_per_tile;
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
+  VF acc1 = (VF)(F)0;
+  VF dacc[PASS == PASS_DOTS ? DCH : 1];
+  if (PASS == PASS_DOTS) {
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) dacc[i] = (VF)(F)0;
+  }
+  for (int tl = bl; tl < rt.tiles_per_xcd; tl += nbl) {
+    const int t = xcd * rt.tiles_per_xcd + tl;
+    const int row0 = t * TR;
+    if (row0 >= n) break;
+    const int c_begin = rt.tile_ptr[t], ncols = rt.tile_ptr[t + 1] - c_begin;
+    // this wave's row-local streams first: their HBM latency overlaps the tile load and the barriers
+    constexpr int MAXR = 2;  // rows per wave and tile: TR <= 16 with 8 waves
+    VF xps[MAXR];
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+      const int row = row0 + wave + q * kWaves;
+      xps[q] = (VF)(F)0;
+      if (!first && wave + q * kWaves < TR && row < n) xps[q] = stream_load<LP>((const VF *)(wp + (int64_t)row * PW));
+    }
+    __syncthreads();  // previous tile fully consumed (and gamma staged)
+    for (int u = wave; u < ncols; u += kWaves) {
+      const int c = rt.tile_cols[c_begin + u];
+      *(VF *)(tile + u * PW + lane * V) = *(const VF *)(wc + (int64_t)c * PW);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+      const int rr = wave + q * kWaves;
+      const int row = row0 + rr;
+      if (rr >= TR || row >= n) break;
+      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+      const int64_t ro = (int64_t)row * PW;
+      const VF xp = xps[q];
+      const VF xc = *(const VF *)(tile + (int)rt.self_idx[row] * PW + lane * V);
+      VF acc = (VF)(F)0;
+      for (int p = p0; p < p1; ++p)
+        acc += vals[p] * *(const VF *)(tile + (int)rt.lidx[p] * PW + lane * V);
+      VF w = sc * acc;
+      if (!first) w -= cp * xp;
+      if (PASS == PASS_ALPHA) {
+        acc1 += (sc * xc) * w;
+      } else {
+        w -= cb * xc;
+        VF u[DCH];
+#pragma unroll
+        for (int i = 0; i < DCH; ++i)
+          if (i < rc) {
+            const int ii = i0 + i;
+            u[i] = (ii == 0) ? xc
+                             : ((ii == 1) ? xp
+                                          : stream_load<LP>((const VF *)(U0 + (int64_t)((j - ii) % S) * slot_stride + ro)));
+          }
+        if (PASS == PASS_DOTS) {
+#pragma unroll
+          for (int i = 0; i < DCH; ++i)
+            if (i < rc) dacc[i] += u[i] * w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < DCH; ++i)
+            if (i < rc) w -= *(const VF *)(gl + i * PW + lane * V) * u[i];
+          stream_store<SP>((VF *)(wn + ro), w);
+          acc1 += w * w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t nblk = gridDim.x;
+  if (PASS == PASS_DOTS) {
+#pragma unroll
+    for (int i = 0; i < DCH; ++i)
+      if (i < rc)
+        block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+  } else {
+    block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+  }
+}
+
 // ---- plain panel SpMM: Y = A X (operator plugin surface; also the dense/CSR matmat entry) -------
 template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_spmm_plain(int n, const int32_t *__restrict__ rowptr,

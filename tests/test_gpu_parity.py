@@ -453,3 +453,19 @@ def test_opt_in_row_reordering_is_transparent(oracle, eng, monkeypatch):
 	numer, denom, _, cnt = acc.get()
 	np.testing.assert_allclose(numer, np.sum((A @ X) * X, axis=1), rtol=1e-9, atol=1e-9)
 	np.testing.assert_allclose(denom, np.sum(X * X, axis=1), rtol=1e-12)
+
+
+def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
+	"""SLQ_TILES=1: the experimental LDS-staged fused passes (k_csr_pass_tiled) give the generic
+	passes' results to rounding, for both tile heights and with/without reorthogonalisation."""
+	A = laplacian_2d(70)  # n = 4900 (not a multiple of the tile height), wide panel (P > 64)
+	rng = np.random.default_rng(9)
+	X = np.asfortranarray(np.floor(rng.random((A.shape[0], 130)) * 2) * 2 - 1)
+	ref = {o: oracle.quad_batch(A, X[:, :6], 14, o, fun="log", fresh_q=True) for o in (0, 3)}
+	for tr in ("16", "8"):
+		monkeypatch.setenv("SLQ_TILES", "1")
+		monkeypatch.setenv("SLQ_TILE_ROWS", tr)
+		op = eng.DeviceOperator(A)
+		for o in (0, 3):
+			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[:6], ref[o], rtol=1e-10)
+		op.close()
