@@ -108,6 +108,7 @@ struct slq_plan {
   slq_profile acc;
   std::vector<char> hbuf;  // host staging for callback operators
   size_t bytes;
+  int nstale;                 // > 0: the reorthogonalisation also sees nstale preloaded vectors t = -1 .. -nstale
   hipGraphExec_t graph_exec;  // the k-step launch sequence captured once per (plan, rtol, variant)
   double graph_rtol;
   int graph_variant;
@@ -729,8 +730,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 
   const size_t ring_bytes = (size_t)p->S * (size_t)p->slot_stride * p->esz;
   const size_t bp = p->bpad;
-  // alpha[deg+1], nu[deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
-  const size_t nscal = ((size_t)(deg + 1) * 2 + 1 + 2 + 1 + (size_t)p->rmax) * bp;
+  // alpha[deg+1], nu[orth margin for stale vectors t < 0 | deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
+  const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + (size_t)p->rmax) * bp;
   const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(p->nblkA, p->nblkU), p->nblkS), p->nblkT) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
@@ -746,6 +747,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->bytes = ring_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + (p->T ? (size_t)p->slot_stride * p->esz : 0);
   double *s = p->scal;
   p->st.alpha = s; s += (size_t)(deg + 1) * bp;
+  s += (size_t)orth * bp;  // nu rows for t = -orth .. -1 (zero unless the drop-in entry preloads stale columns)
   p->st.nu = s; s += (size_t)(deg + 1) * bp;
   p->st.vnorm2 = s; s += bp;
   p->st.coefA = s; s += 2 * bp;
@@ -761,6 +763,14 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->graph_exec = nullptr;
   p->graph_rtol = 0.0;
   p->graph_variant = -1;
+  p->nstale = 0;
+  {
+    hipError_t ze = hipMemsetAsync(p->scal, 0, nscal * 8, ctx->stream);
+    if (ze != hipSuccess) {
+      slq_plan_destroy(p);
+      return fail(SLQ_EHIP, "workspace clear: %s", hipGetErrorString(ze));
+    }
+  }
   {
     const int rc = set_kernel_attributes(p);
     if (rc != SLQ_OK) {
@@ -947,6 +957,7 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
 }
 
 static int launch_reorth_update(slq_plan *p, int j, int r, int istart);
+static int launch_reorth_update_range(slq_plan *p, int j, int ibegin, int iend);
 static int update_chunk_cols(const slq_plan *p);
 
 // probes per workgroup of the QL kernel: 3*deg*lanes doubles of LDS, at most 150 KiB
@@ -972,9 +983,15 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
   for (int j = 0; j < deg; ++j) {
     const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
     const int first = (j == 0);
-    const int r = p->orth > 0 ? std::min(j + 1, p->orth) : 0;
+    // reorth columns: the last `orth` ring vectors; before step orth-1 only j+1 exist, unless the
+    // drop-in entry preloaded the caller's stale ring columns as vectors t < 0 (lanczos_single)
+    const int r = p->orth > 0 ? std::min(j + 1 + p->nstale, p->orth) : 0;
     int nblk_last = p->nblkS;
-    if (op->kind == OP_CSR && fused && r <= kFusedMaxR) {
+    // exact modified Gram-Schmidt order (one ring column at a time, each dot taken on the updated w):
+    // used when stale ring columns take part, whose projections are NOT small, so block-CGS and the
+    // reference's MGS would differ at second order (1e-6..1e-5 measured with 18 stale vectors)
+    const bool mgs = p->nstale > 0 || env_int("SLQ_MGS", 0) != 0;
+    if (op->kind == OP_CSR && fused && r <= kFusedMaxR && !mgs) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
@@ -1056,6 +1073,18 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
                         (k_axpy_norm<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n,
                                             (F *)slot_ptr(p, sn_), (const F *)slot_ptr(p, sc_),
                                             p->st.coefB, p->part, bp))));
+    } else if (mgs) {
+      for (int i = 0; i < r; ++i) {
+        PROFILED(p, SLQ_K_REORTH_DOT,
+                 DISPATCH(p->dtype, p->LPR,
+                          (k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                                              (F *)p->ring, p->slot_stride, S, j, i, 1, (int)(i == 0),
+                                              p->st.coefB, p->part, bp))));
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, 1), dim3(kFinThreads), 0, st, p->st,
+                                    p->part, p->nblkS, j, i, orth_tol));
+        SLQ_TRY(launch_reorth_update_range(p, j, i, i + 1));
+      }
     } else {
       for (int i0 = 0; i0 < r; i0 += kReorthChunk) {
         const int rc = std::min(kReorthChunk, r - i0);
@@ -1093,7 +1122,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!graph_ok) {
     SLQ_TRY(enqueue_run(p, rtol, fused, nt));
   } else {
-    const int variant = (fused ? 1 : 0) | (nt ? 2 : 0);
+    const int variant = (fused ? 1 : 0) | (nt ? 2 : 0) | (p->nstale << 2);
     if (!p->graph_exec || p->graph_rtol != rtol || p->graph_variant != variant) {
       if (p->graph_exec) {
         HIP_TRY(hipGraphExecDestroy(p->graph_exec));
@@ -1212,7 +1241,7 @@ static int update_chunk_cols(const slq_plan *p) {
 }
 
 // w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
-static int launch_reorth_update(slq_plan *p, int j, int r, int istart) {
+static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r) {
   hipStream_t st = p->ctx->stream;
   const int V = p->dtype == SLQ_F64 ? 2 : 4;
   const int kUpdChunk = update_chunk_cols(p);
@@ -1228,6 +1257,8 @@ static int launch_reorth_update(slq_plan *p, int j, int r, int istart) {
   }
   return SLQ_OK;
 }
+
+static int launch_reorth_update(slq_plan *p, int j, int r, int istart) { return launch_reorth_update_range(p, j, istart, r); }
 
 // Y = f(A) X on the device: result left in ring slot `deg` (panel layout)
 static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) {
@@ -1558,6 +1589,44 @@ static int lanczos_single(slq_context *ctx, slq_operator *op, F *v, int deg, F r
   slq_plan *p = nullptr;
   SLQ_TRY(slq_plan_create(ctx, op, 1, deg, orth, keep, &p));
   int rc = slq_plan_set_probes(p, v, n);
+  // Stale ring columns. The reference clears only column ncv-1 and writes column 0 on entry
+  // (lanczos.h:118-120); during the first orth-1 steps its MGS sweep also walks columns ncv-1,
+  // ncv-2, ... ncv-orth+1 with whatever the caller left there (lanczos.h:58 with reverse indices),
+  // e.g. the previous probe's Lanczos vectors when MatrixFunction.quad reuses its Q
+  // (operators.py:138-148). Reproduce that: those columns become vectors t = -1, -2, ... of the
+  // ring (t = -1 is the cleared column), with nu_t = ||column||.
+  const int nst = (rc == SLQ_OK && p->orth >= 2) ? p->orth - 1 : 0;
+  if (nst > 0) {
+    hipStream_t st = ctx->stream;
+    std::vector<double> norms((size_t)nst + 1, 0.0);
+    bool any = false;
+    for (int k = 2; k <= nst && rc == SLQ_OK; ++k) {  // t = -k  <->  caller column ncv - k
+      const F *col = Q + (size_t)(ncv - k) * n;
+      double s2 = 0.0;
+      for (int i = 0; i < n; ++i) s2 += (double)col[i] * (double)col[i];
+      norms[(size_t)k] = std::sqrt(s2);
+      if (s2 > 0.0) any = true;
+    }
+    if (any) {
+      rc = ensure_stage(p, 1);
+      for (int k = 1; k <= nst && rc == SLQ_OK; ++k) {
+        const int slot = p->S - k;
+        hipError_t e = hipMemsetAsync(slot_ptr(p, slot), 0, (size_t)p->slot_stride * p->esz, st);
+        if (e == hipSuccess && k >= 2 && norms[(size_t)k] > 0.0) {
+          e = hipMemcpyAsync(p->stage, Q + (size_t)(ncv - k) * n, (size_t)n * sizeof(F), hipMemcpyHostToDevice, st);
+          if (e == hipSuccess) {
+            dim3 g((n + 63) / 64, 1);
+            k_cols_to_panel<F><<<g, dim3(256), 0, st>>>(n, (const F *)p->stage, 0, 1, (F *)slot_ptr(p, slot), p->PW, op->perm_d);
+            e = hipStreamSynchronize(st);
+          }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(p->st.nu - (size_t)k * p->bpad, &norms[(size_t)k], sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SLQ_EHIP, "stale ring upload: %s", hipGetErrorString(e));
+      }
+      if (rc == SLQ_OK) p->nstale = nst;
+    }
+  }
   if (rc == SLQ_OK) rc = slq_plan_run(p, (double)rtol);
   std::vector<F> a(deg + 1), b(deg + 1);
   int32_t steps = 0;

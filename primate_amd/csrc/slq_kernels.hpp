@@ -60,6 +60,14 @@ constexpr int kFusedMaxR = 4;        // fused recompute passes handle up to this
 #define SLQ_UPD_UR 2
 #endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
 
+// Slot of Lanczos vector t in a ring of S slots. t may be negative: vectors "before the run" are the
+// caller's stale ring columns of the single-vector drop-in entry (slq.hip:lanczos_single), stored
+// at the far end of the ring.
+__device__ __forceinline__ int ring_slot(int t, int S) {
+  const int m = t % S;
+  return m < 0 ? m + S : m;
+}
+
 template <typename F, int LPR> struct Geo {
   static constexpr int V = VecT<F>::V;
   static constexpr int PW = LPR * V;   // probes per panel row
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
             const int ii = i0 + i;
             u[i] = (ii == 0) ? xc
                              : ((ii == 1) ? xp
-                                          : stream_load<LP>((const VF *)(U0 + (int64_t)((j - ii) % S) * slot_stride + ro)));
+                                          : stream_load<LP>((const VF *)(U0 + (int64_t)ring_slot(j - ii, S) * slot_stride + ro)));
           }
         if (PASS == PASS_DOTS) {
 #pragma unroll
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
             const int ii = i0 + i;
             u[i] = (ii == 0) ? xc
                              : ((ii == 1) ? xp
-                                          : stream_load<LP>((const VF *)(U0 + (int64_t)((j - ii) % S) * slot_stride + ro)));
+                                          : stream_load<LP>((const VF *)(U0 + (int64_t)ring_slot(j - ii, S) * slot_stride + ro)));
           }
         if (PASS == PASS_DOTS) {
 #pragma unroll
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
     VF u[kReorthChunk];
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
-      if (i < rc) u[i] = *(const VF *)(U0 + (int64_t)((j - i0 - i) % S) * slot_stride + ro);
+      if (i < rc) u[i] = *(const VF *)(U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride + ro);
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
       if (i < rc) dacc[i] += u[i] * w;
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       w[u] = *(const VF *)(W + ro[u]);
     }
     for (int i = 0; i < r; ++i) {
-      const F *U = U0 + (int64_t)((j - i0 - i) % S) * slot_stride;
+      const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
       const VF gm = *(const VF *)(gl + i * PW + cl * V);
       VF x[UR];
 #pragma unroll

@@ -49,9 +49,20 @@ class MatrixFunction(LinearOperator):
 	Parameters match the reference: A (ndarray / sparse / LinearOperator), fun (name or callable),
 	deg, orth (number of most recent Lanczos vectors to re-orthogonalise against; <0 or >deg means
 	deg), dtype, and **kwargs for the named function (e.g. t=, a=, b=, threshold=).
+
+	stale_ring (extra, default False): reproduce the reference's `quad` bit of history — it never
+	clears its Lanczos ring `_Q` between probes (operators.py:138-148), so with orth > 0 probe j's
+	first orth-1 reorthogonalisation sweeps also project against probe j-1's last Lanczos vectors.
+	True runs `quad` one probe at a time through the single-vector drop-in entry with a persistent
+	ring, exactly like the reference (and as slowly: one device run per probe). The default False is
+	the lock-step batched path, which starts every probe from a clean ring — what the reference's own
+	`_matvec` enforces (operators.py:116) and what its first probe always sees.
 	"""
 
-	def __init__(self, A, fun: Union[str, Callable, None] = None, deg: int = 20, orth: int = 3, dtype: np.dtype = F64, **kwargs) -> None:
+	def __init__(
+		self, A, fun: Union[str, Callable, None] = None, deg: int = 20, orth: int = 3, dtype: np.dtype = F64,
+		stale_ring: bool = False, **kwargs,
+	) -> None:  # fmt: skip
 		assert is_linear_op(A), "Invalid operator `A`; must be dim=2 symmetric operator with defined matvec"
 		assert deg >= 2, "Degree must be >= 2"
 		self.shape = A.shape
@@ -65,6 +76,11 @@ class MatrixFunction(LinearOperator):
 		self._A = A
 		self._op = _as_device_operator(A, dtype=self.dtype)
 		self._plans: dict = {}
+		self._stale_ring = bool(stale_ring)
+		if self._stale_ring:  # the reference's persistent buffers (operators.py:69-77)
+			self._alpha = np.zeros(self._deg + 1, dtype=self.dtype)
+			self._beta = np.zeros(self._deg + 1, dtype=self.dtype)
+			self._Q = np.zeros((A.shape[0], self._deg), dtype=self.dtype, order="F")
 		self._nodes = np.zeros(self._deg, dtype=self.dtype)
 		self._weights = np.zeros(self._deg, dtype=self.dtype)
 
@@ -106,6 +122,8 @@ class MatrixFunction(LinearOperator):
 		"""x^T f(A) x for every column of x by Lanczos quadrature (operators.py:126-151)."""
 		x = np.asarray(x).astype(self.dtype)
 		x = np.atleast_2d(x).T if x.ndim == 1 else x
+		if self._stale_ring:
+			return self._quad_reference_ring(x)
 		plan = self._plan(x.shape[1], False)
 		plan.set_probes(x)
 		plan.run(self._rtol)
@@ -116,6 +134,20 @@ class MatrixFunction(LinearOperator):
 			y, nodes, weights = plan.quadrature(self._fun, return_rule=True)
 		## the reference leaves the last probe's rule in self._nodes/_weights (operators.py:149)
 		self._nodes[:], self._weights[:] = nodes[-1], weights[-1]
+		return y
+
+	def _quad_reference_ring(self, x: np.ndarray) -> np.ndarray:
+		"""The reference loop verbatim in structure (operators.py:145-150): per column, the native
+		single-vector Lanczos on the persistent alpha/beta/Q, then the Gauss rule, then the sum."""
+		from .integrate import quadrature
+		from .lanczos import _native_lanczos
+
+		y = np.zeros(x.shape[1])
+		for j in range(x.shape[1]):
+			xc = np.ascontiguousarray(x[:, j])
+			_native_lanczos(self._op, xc, self._deg, self._rtol, self._orth, self._alpha, self._beta, self._Q)
+			quadrature(self._alpha[: self._deg], self._beta[: self._deg], deg=self._deg, nodes=self._nodes, weights=self._weights)
+			y[j] = np.sum(self._fun(self._nodes) * self._weights, axis=-1) * np.linalg.norm(xc) ** 2
 		return y
 
 	def _matvec(self, x: np.ndarray) -> np.ndarray:

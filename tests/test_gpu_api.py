@@ -208,3 +208,50 @@ def test_fttr_quadrature_on_device():
 	th, w = quadrature(a, b, deg=15, quad="fttr")
 	np.testing.assert_allclose(th, gd["fttr_nodes"], atol=1e-13)
 	np.testing.assert_allclose(w, gd["fttr_weights"], rtol=1e-9)
+
+
+def test_stale_ring_compat_reproduces_reference_quad(oracle, golden):
+	"""The reference's MatrixFunction.quad carries probe j-1's Lanczos vectors into probe j's
+	reorthogonalisation. stale_ring=True reproduces it through the single-vector
+	drop-in entry. The chain is numerically unstable for partial reorthogonalisation: rounding
+	differences between two correct implementations grow ~50x per probe (measured: 1e-14, 2e-13,
+	1e-11 in alpha for probes 0, 1, 2), so exact agreement with the reference's own sequence
+	("injected" golden) is only meaningful for the first probes; later ones agree to ~1e-3."""
+	from primate_amd.lanczos import _native_lanczos
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch
+
+	L, V = laplacian_2d(int(golden["lap_m"])), golden["lap_probes"]
+	M = MatrixFunction(L, fun="log", deg=20, orth=0, stale_ring=True)
+	np.testing.assert_allclose(M.quad(V.copy()), golden["mf_quad_log_o0"], rtol=1e-10)  # orth = 0: no ring effect
+	for orth in (3, 20):
+		M = MatrixFunction(L, fun="log", deg=20, orth=orth, stale_ring=True)
+		q, ref, clean = M.quad(V.copy()), golden[f"mf_quad_log_o{orth}"], golden[f"lap_quad_log_o{orth}"]
+		np.testing.assert_allclose(q[:3], ref[:3], rtol=1e-8)
+		np.testing.assert_allclose(q, ref, rtol=2e-3)
+		## it really is the stale behaviour that is reproduced, not the clean one
+		assert np.max(np.abs(q[1:3] / clean[1:3] - 1)) > 1e-4 and np.max(np.abs(q[1:3] / ref[1:3] - 1)) < 1e-8
+	## the batched default equals the cleared-ring values (pure golden)
+	M = MatrixFunction(L, fun="log", deg=20, orth=3)
+	np.testing.assert_allclose(M.quad(V.copy()), golden["lap_quad_log_o3"], rtol=1e-10)
+	## hutch over the compat operator vs the reference's hutch(MatrixFunction, orth = 3), same call
+	## sequence as tests/golden/make_golden.py (two runs on ONE operator: the second starts from the
+	## ring the first one left). 40- and 80-probe chains: agreement to the chain's stability.
+	for fun in ("log", "exp"):
+		M = MatrixFunction(L, fun=fun, deg=20, orth=3, stale_ring=True)
+		assert hutch(M, converge="count", count=40, seed=1234) == pytest.approx(float(golden[f"hutch_mf_{fun}_c40"]), rel=1e-3)
+		est, info = hutch(M, converge="count", count=40, seed=1234, full=True, batch=8, record=True)
+		assert est == pytest.approx(float(golden[f"hutch_mf_{fun}_c40_full"]), rel=1e-3)
+		np.testing.assert_allclose(np.ravel(info.estimator.values), golden[f"hutch_mf_{fun}_c40_samples"], rtol=2e-2)
+	## the native entry against the oracle with the SAME dirty ring on both sides (one call: stable).
+	## With stale columns present the device loop switches to exact MGS order (slq.hip: mgs).
+	rng = np.random.default_rng(3)
+	for orth, ncv, tol in [(3, 20, 1e-10), (2, 2, 1e-10), (20, 20, 1e-9), (5, 7, 1e-9)]:
+		Q0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((L.shape[0], ncv)))[0])
+		al, be, Q = np.zeros(21), np.zeros(21), Q0.copy(order="F")
+		al2, be2, Q2 = np.zeros(21), np.zeros(21), Q0.copy(order="F")
+		s1 = _native_lanczos(L, V[:, 1], 20, 1e-8, orth, al, be, Q)
+		s2 = oracle.lanczos(L, V[:, 1], 20, 1e-8, orth, al2, be2, Q2)
+		assert s1 == s2
+		np.testing.assert_allclose(al, al2, rtol=tol, atol=tol)
+		np.testing.assert_allclose(be, be2, rtol=tol, atol=tol)
