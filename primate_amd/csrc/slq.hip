@@ -921,10 +921,41 @@ extern "C" int slq_plan_get_probes(slq_plan *p, void *X, int64_t ldx) {
   return panel_to_host(p, 0, 0, p->nprobes, X, ldx, nullptr);
 }
 
+
+// fp64 dense operator on MFMA: Wn = sc*(A Wc) - cp*Wp with alpha partials (plain = 0), or Wn = A Wc
+static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *Wn, int first, int plain, int *nblk_out) {
+  const slq_operator *op = p->op;
+  hipStream_t st = p->ctx->stream;
+  const int nblk = (p->n + 15) / 16;
+  if ((size_t)nblk > (size_t)kReorthChunk * std::max(std::max(std::max(p->nblkA, p->nblkU), p->nblkS), p->nblkT))
+    return fail(SLQ_EINVAL, "dense operator too large for the partials buffer");
+  const dim3 g(nblk, p->NP);
+#define DENSE_LAUNCH(TWV, COL0)                                                                             \
+  {                                                                                                         \
+    const size_t lds = ((size_t)kWaves * (TWV / 16) * 4 * 64 + (size_t)TWV * 4) * sizeof(double);          \
+    HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<TWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    k_dense_mfma_3term<TWV><<<g, dim3(kBlock), lds, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc,        \
+                                                        (const double *)Wp, (double *)Wn, p->st.coefA, p->part, p->bpad, first, plain, p->PW, COL0); \
+  }
+  switch (p->PW) {
+    case 128: DENSE_LAUNCH(64, 0) DENSE_LAUNCH(64, 64) break;  // two 64-column halves: A streamed twice, LDS 64 KiB
+    case 64: DENSE_LAUNCH(64, 0) break;
+    case 32: DENSE_LAUNCH(32, 0) break;
+    default: DENSE_LAUNCH(16, 0) break;
+  }
+#undef DENSE_LAUNCH
+  if (nblk_out) *nblk_out = nblk;
+  return SLQ_OK;
+}
+
 // T = A * (slot c), unscaled, for operators without a fused kernel
 static int apply_operator_unfused(slq_plan *p, int slot_c) {
   hipStream_t st = p->ctx->stream;
   slq_operator *op = p->op;
+  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && env_int("SLQ_DENSE_MFMA", 1) != 0) {
+    PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, slot_c), nullptr, p->T, 1, 1, nullptr)));
+    return SLQ_OK;
+  }
   if (op->kind == OP_DENSE) {
     dim3 g(std::max(1, std::min(p->ctx->num_cus * 2, (p->n + kWaves - 1) / kWaves)), p->NP);
     PROFILED(p, SLQ_K_SPMM,
@@ -1056,6 +1087,11 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
 #undef SPMM_LAUNCH
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
+    } else if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && env_int("SLQ_DENSE_MFMA", 1) != 0) {
+      int nb = 0;
+      PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, sc_), slot_ptr(p, sp_), slot_ptr(p, sn_), first, 0, &nb)));
+      PROFILED(p, SLQ_K_FINALIZE,
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, nb, j));
     } else {
       SLQ_TRY(apply_operator_unfused(p, sc_));
       PROFILED(p, SLQ_K_AXPY_NORM,

@@ -500,6 +500,90 @@ __global__ __launch_bounds__(kBlock) void k_dense_panel(int n, const F *__restri
   }
 }
 
+// ---- dense operator on the matrix cores: Y = A W_c as an fp64 MFMA panel GEMM, fused three-term ----
+// The one GEMM-shaped product on this path: a dense symmetric A (n x n, column-major) times a probe
+// panel (n x PW): 2 n^2 PW flops on n^2 matrix elements — 16..32 flop per byte of A, so the kernel
+// should stream A at the HBM rate with v_mfma_f64_16x16x4_f64 doing the arithmetic. (The VALU kernel
+// k_dense_panel re-reads the whole panel from L2 for every output row: 0.97 ms per product at
+// n = 5000, PW = 64, i.e. 0.2 TB/s on A.)
+// Workgroup = 16 output rows x all PW columns; its 8 waves split K = n eight ways (split-K, so that
+// n/16 workgroups x 8 waves fill the chip at n = 5000) and are summed through LDS in wave order.
+// Fragments (cdna_hip_programming.md §3, f64 layout): lane l holds A[m = l&15][k = l>>4] and
+// B[k = l>>4][n = l&15]; the accumulator's 4 f64 are rows (l>>4) + 4*reg of column l&15.
+// A is symmetric, so A[m][k] is read as element (k, m) of the column-major array: 16 contiguous
+// doubles per k. Epilogue as k_3term: w = sc*acc - cp*W_p; alpha partial += (sc*W_c)*w.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// TW = columns handled per launch (<= 64 keeps the split-K LDS image at 64 KiB: 2 workgroups per CU);
+// ldw = panel row stride (PW), col0 = first column of this launch inside the panel.
+template <int TW>
+__global__ __launch_bounds__(kBlock) void k_dense_mfma_3term(
+    int n, const double *__restrict__ A, int64_t lda, const double *Wc, const double *Wp, double *Wn,
+    const double *__restrict__ coefA, double *__restrict__ partA, int bpad, int first, int plain, int ldw,
+    int col0) {
+  constexpr int NT = TW / 16;  // 16-column accumulator tiles per wave
+  const int PW = ldw;
+  extern __shared__ __attribute__((aligned(16))) double lds_acc[];  // [kWaves][NT][4][64] split-K partial tiles
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int panel = blockIdx.y;
+  const int r0 = blockIdx.x * 16;
+  const int64_t poff = (int64_t)panel * n * PW;
+  const double *wc = Wc + poff;
+  d4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4_t)0.0;
+  // this wave's K slice, in multiples of 4
+  const int kq = (n + 3) / 4;                       // number of k-quads
+  const int per = (kq + kWaves - 1) / kWaves;
+  const int q_begin = wave * per, q_end = min(kq, q_begin + per);
+  const bool row_ok = (r0 + lr) < n;
+  for (int q = q_begin; q < q_end; ++q) {
+    const int k = q * 4 + lk;
+    const bool k_ok = k < n;
+    const double a = (row_ok && k_ok) ? A[(int64_t)k * lda + r0 + lr] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double b = k_ok ? wc[(int64_t)k * PW + col0 + t * 16 + lr] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  // split-K reduction through LDS, wave order fixed
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_acc[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  // wave w finishes tiles t = w, w + 8, ...: sum the 8 partials, apply the epilogue
+  double *alpha_red = lds_acc + kWaves * NT * 4 * 64;  // [TW][4 row groups]
+  for (int t = wave; t < NT; t += kWaves) {
+    const int col = col0 + t * 16 + lr;
+    const int gc = panel * PW + col;
+    const double sc = plain ? 1.0 : coefA[gc], cp = plain ? 0.0 : coefA[bpad + gc];
+    double apart = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double u = 0.0;
+      for (int w = 0; w < kWaves; ++w) u += lds_acc[((w * NT + t) * 4 + r) * 64 + lane];
+      const int row = r0 + lk + 4 * r;
+      if (row < n) {
+        const int64_t off = poff + (int64_t)row * PW + col;
+        double wv = sc * u;
+        if (!first && !plain) wv -= cp * Wp[off];
+        if (!plain) apart += (sc * Wc[off]) * wv;
+        Wn[off] = wv;
+      }
+    }
+    alpha_red[(col - col0) * 4 + lk] = apart;
+  }
+  __syncthreads();
+  if (!plain && (int)threadIdx.x < TW) {
+    const int c = threadIdx.x;
+    partA[(int64_t)blockIdx.x * bpad + panel * PW + col0 + c] =
+        (alpha_red[c * 4] + alpha_red[c * 4 + 1]) + (alpha_red[c * 4 + 2] + alpha_red[c * 4 + 3]);
+  }
+}
+
 // Three-term epilogue for operators whose product is computed by a separate kernel (dense,
 // host callback): in: T = A (Wc) unscaled. w = sc*T - cp*Wp ; partA += (sc*Wc) * w ; Wn = w.
 template <typename F, int LPR>
