@@ -280,16 +280,16 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
 }
 
 
-// Row tiles for k_csr_pass_tiled: per tile of TR consecutive rows, the sorted list of distinct
-// columns (plus the rows themselves) and, per nonzero, its position in that list. Built once on the
-// host from the (possibly reordered) CSR arrays. Returns false if even TR = 8 needs more than
-// `cap` panel rows of LDS per tile (irregular / random sparsity: no reuse to exploit, generic path).
+// Row tiles for k_csr_pass_tiled: per tile of TR consecutive rows (one wave's unit of work), the sorted
+// list of distinct columns (plus the rows themselves) and, per nonzero, its position in that list.
+// Built once on the host from the (possibly reordered) CSR arrays. Returns false if even TR = 2 needs
+// more than `cap` distinct panel rows per tile (irregular / random sparsity: no reuse, generic path).
 static bool build_row_tiles(int64_t n, const int32_t *rowptr, const int32_t *colind, int cap, int *TR_out,
                             std::vector<int32_t> &tile_ptr, std::vector<int32_t> &tile_cols,
                             std::vector<uint16_t> &lidx, std::vector<uint16_t> &self_idx, int *tiles_per_xcd,
                             int *max_cols) {
   const int forced = env_int("SLQ_TILE_ROWS", 0);
-  for (int TR : {16, 8}) {
+  for (int TR : {4, 2}) {
     if (forced && TR != forced) continue;
     const int64_t ntiles_real = (n + TR - 1) / TR;
     const int tpx = (int)((ntiles_real + 7) / 8);
@@ -402,15 +402,14 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     slq_operator_destroy(op);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
   }
-  // LDS row tiles (wide-panel fused passes). EXPERIMENTAL, off by default: the barrier-coupled
-  // load -> compute structure of k_csr_pass_tiled exposes one HBM latency per tile and ran 2x SLOWER
-  // than the generic passes on configs[1] (2.1 vs 0.98 ms for the alpha pass). It is
-  // the scaffold for a double-buffered LDS-DMA version; SLQ_TILES=1 enables it.
+  // LDS row tiles (wide-panel fused passes). EXPERIMENTAL, off by default: measured 1.7x SLOWER than the
+  // generic passes on configs[1] (1.6 vs 0.93 ms for the alpha pass): the 1-KiB-row LDS
+  // images cap residency at 8 waves per CU. SLQ_TILES=1 enables it (kept tested).
   if (env_int("SLQ_TILES", 0) != 0 && nnz > 0) {
     std::vector<int32_t> tp, tc;
     std::vector<uint16_t> li, si;
     int TR = 0, tpx = 0, mx = 0;
-    const int cap = env_int("SLQ_TILE_CAP", 64);  // panel rows (1 KiB each) of LDS per tile: 2 workgroups per CU
+    const int cap = 16;  // distinct panel rows per wave-private tile (registers + 16 KiB of LDS per wave)
     if (build_row_tiles(n, rowptr, colind, cap, &TR, tp, tc, li, si, &tpx, &mx)) {
       int32_t *d_tp = nullptr, *d_tc = nullptr;
       uint16_t *d_li = nullptr, *d_si = nullptr;
@@ -719,8 +718,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
   {
-    // tiled passes: 2 workgroups per CU resident (LDS-limited), one panel at a time
-    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", 2));
+    // tiled passes: 1 workgroup per CU resident (8 wave-private LDS images), one panel at a time
+    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", 1));
     int per_xcd_t = std::max(1, ctx->num_cus * per_cu_t / 8);
     if (op->tiles.tile_ptr) per_xcd_t = std::min(per_xcd_t, std::max(1, op->tiles.tiles_per_xcd));
     p->nblkT = 8 * per_xcd_t;
@@ -1029,7 +1028,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       const int fused_alpha_pad = 65536;
       // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
       const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0;
-      const size_t lds_tile = tiled ? (size_t)op->tiles.max_cols * p->PW * p->esz : 0;
+      const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS)                                                          \
   do {                                                                                               \
     if (tiled) {                                                                                     \
@@ -1051,7 +1050,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       // alpha pass: its 58 VGPRs would admit 4 workgroups per CU; 2 resident ones (64 KiB of LDS padding)
       // keep the rows in flight per XCD at 512 and the panels strictly one after the other, which
       // measured 4-5 % faster than 4 per CU (0.92 vs 0.96 ms) and fetches less
-      const size_t ldsA = lds0 + (size_t)env_int("SLQ_ALPHA_LDS_PAD", fused_alpha_pad);
+      const size_t ldsA = lds0 + (tiled ? 0 : (size_t)env_int("SLQ_ALPHA_LDS_PAD", fused_alpha_pad));
       PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA); });
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkA, j));

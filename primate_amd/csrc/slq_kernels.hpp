@@ -336,8 +336,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double *red = (double *)lds_raw;                                  // kWaves*64*V doubles
   F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);        // PASS_UPDATE: rc * PW
-  F *tile = gl + (PASS == PASS_UPDATE ? rc * PW : 0);               // max_cols * PW
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // WAVE-PRIVATE tile image: no workgroup barrier inside the row loop, every wave runs its own
+  // load -> compute chain (the barrier-coupled version exposed one HBM latency per tile and workgroup)
+  F *tile = gl + (PASS == PASS_UPDATE ? rc * PW : 0) + (size_t)wave * rt.max_cols * PW;
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + lane * V;
   const int first = (j == 0);
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
   if (PASS == PASS_UPDATE) {
     for (int t = threadIdx.x; t < rc * PW; t += kBlock)
       gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+    __syncthreads();
   }
   const int TR = rt.rows_per_tile;
   const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
@@ -365,34 +368,53 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
 #pragma unroll
     for (int i = 0; i < DCH; ++i) dacc[i] = (VF)(F)0;
   }
-  for (int tl = bl; tl < rt.tiles_per_xcd; tl += nbl) {
-    const int t = xcd * rt.tiles_per_xcd + tl;
-    const int row0 = t * TR;
-    if (row0 >= n) break;
-    const int c_begin = rt.tile_ptr[t], ncols = rt.tile_ptr[t + 1] - c_begin;
-    // this wave's row-local streams first: their HBM latency overlaps the tile load and the barriers
-    constexpr int MAXR = 2;  // rows per wave and tile: TR <= 16 with 8 waves
-    VF xps[MAXR];
+  // Software pipeline over this wave's tiles: the global loads of tile k+1 (distinct panel rows and the
+  // row-local W_p rows) are issued BEFORE tile k is consumed from the LDS image and are parked in the
+  // image only afterwards, so their HBM/L2 latency overlaps the compute of tile k.
+  constexpr int MAXC = 16, MAXTR = 4;
+  const int tstep = nbl * kWaves;
+  int tl = bl * kWaves + wave;
+  VF xs[MAXC], xpn[MAXTR];
+  int ncols_n = 0, row0_n = n;
+  auto issue = [&](int tli) {
+    ncols_n = 0;
+    row0_n = n;
+    if (tli < rt.tiles_per_xcd) {
+      const int t = __builtin_amdgcn_readfirstlane(xcd * rt.tiles_per_xcd + tli);
+      if (t * TR < n) {
+        row0_n = t * TR;
+        const int c_begin = rt.tile_ptr[t];
+        ncols_n = rt.tile_ptr[t + 1] - c_begin;
 #pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      const int row = row0 + wave + q * kWaves;
-      xps[q] = (VF)(F)0;
-      if (!first && wave + q * kWaves < TR && row < n) xps[q] = stream_load<LP>((const VF *)(wp + (int64_t)row * PW));
-    }
-    __syncthreads();  // previous tile fully consumed (and gamma staged)
-    for (int u = wave; u < ncols; u += kWaves) {
-      const int c = rt.tile_cols[c_begin + u];
-      *(VF *)(tile + u * PW + lane * V) = *(const VF *)(wc + (int64_t)c * PW);
-    }
-    __syncthreads();
+        for (int u = 0; u < MAXC; ++u)
+          if (u < ncols_n) xs[u] = *(const VF *)(wc + (int64_t)rt.tile_cols[c_begin + u] * PW);
 #pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      const int rr = wave + q * kWaves;
+        for (int q = 0; q < MAXTR; ++q) {
+          xpn[q] = (VF)(F)0;
+          if (!first && q < TR && row0_n + q < n) xpn[q] = stream_load<LP>((const VF *)(wp + (int64_t)(row0_n + q) * PW));
+        }
+      }
+    }
+  };
+  issue(tl);
+  while (row0_n < n) {
+    // park the prefetched tile in the LDS image
+    const int row0 = row0_n, ncols = ncols_n;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u)
+      if (u < ncols) *(VF *)(tile + u * PW + lane * V) = xs[u];
+    VF xpc[MAXTR];
+#pragma unroll
+    for (int q = 0; q < MAXTR; ++q) xpc[q] = xpn[q];
+    tl += tstep;
+    issue(tl);  // next tile's loads fly while this one is consumed
+#pragma unroll
+    for (int rr = 0; rr < MAXTR; ++rr) {
       const int row = row0 + rr;
       if (rr >= TR || row >= n) break;
       const int p0 = rowptr[row], p1 = rowptr[row + 1];
       const int64_t ro = (int64_t)row * PW;
-      const VF xp = xps[q];
+      const VF xp = xpc[rr];
       const VF xc = *(const VF *)(tile + (int)rt.self_idx[row] * PW + lane * V);
       VF acc = (VF)(F)0;
       for (int p = p0; p < p1; ++p)

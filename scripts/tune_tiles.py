@@ -6,7 +6,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from conftest import laplacian_2d
 from primate_amd.engine import DeviceOperator, LanczosPlan
 L2 = laplacian_2d(1000)
-for tiles, tr, bt in [(0, 0, 2), (1, 16, 2), (1, 8, 2), (1, 8, 4), (1, 8, 5), (1, 8, 3)]:
+for tiles, tr, bt in [(1, 4, 1), (1, 2, 1)]:
     os.environ["SLQ_TILES"] = str(tiles); os.environ["SLQ_TILE_ROWS"] = str(tr); os.environ["SLQ_BLOCKS_PER_CU_TILED"] = str(bt)
     t0 = time.time(); op = DeviceOperator(L2); tup = time.time() - t0
     for orth in [0, 3]:

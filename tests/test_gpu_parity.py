@@ -462,7 +462,7 @@ def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 	rng = np.random.default_rng(9)
 	X = np.asfortranarray(np.floor(rng.random((A.shape[0], 130)) * 2) * 2 - 1)
 	ref = {o: oracle.quad_batch(A, X[:, :6], 14, o, fun="log", fresh_q=True) for o in (0, 3)}
-	for tr in ("16", "8"):
+	for tr in ("4", "2"):
 		monkeypatch.setenv("SLQ_TILES", "1")
 		monkeypatch.setenv("SLQ_TILE_ROWS", tr)
 		op = eng.DeviceOperator(A)
