@@ -76,6 +76,7 @@ typedef struct slq_context slq_context;   /* one per (process, GPU): device id +
 typedef struct slq_operator slq_operator; /* a symmetric linear operator resident on that GPU    */
 typedef struct slq_plan slq_plan;         /* workspace + state of one batched Lanczos run        */
 typedef struct slq_diag slq_diag;         /* device-resident accumulators of the diagonal estimator */
+typedef struct slq_dmat slq_dmat;         /* column-major n x m fp64 matrix resident on the device  */
 
 /* Host-callback operator: y = A x on HOST memory (the fallback for arbitrary Python
  * LinearOperators; mirrors PyLinearOperator::matvec, src/primate/include/pylinop.h:32-40).
@@ -165,6 +166,23 @@ int slq_plan_fun_action(slq_plan *plan, int fun_id, const double *fun_params, vo
 int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e,
                          int fun_id, const double *fun_params, double *quad, double *nodes,
                          double *weights);
+
+/* Tall-skinny dense algebra for the exchangeable estimators (xtrace / hutch++: the host-side
+ * np.linalg.qr, Q.T @ W, Z.T @ W, ... of src/primate/trace.py:160-176,199-227,296-302) on the matrix
+ * cores (fp64 MFMA). Matrices are column-major n x cols with leading dimension n.
+ *   gemm_tn: C (ma x mb, row-major, host) = A[:, a0:a0+ma]^T  B[:, b0:b0+mb]
+ *   gemm_nn: OUT[:, o0:o0+mb] = beta * OUT[:, o0:o0+mb] + alpha * A[:, a0:a0+ma] * C  (C: ma x mb row-major host)
+ *   slq_plan_fun_action_dmat: f(A) X of a completed keep_basis run straight into OUT's columns;
+ *   slq_dmat_ptr + slq_plan_set_probes_device feed a matrix's columns back in as probes. */
+int slq_dmat_create(slq_context *ctx, int64_t n, int cols, slq_dmat **out);
+int slq_dmat_destroy(slq_dmat *m);
+int slq_dmat_set(slq_dmat *m, int c0, int nc, const double *host, int64_t ld);
+int slq_dmat_get(slq_dmat *m, int c0, int nc, double *host, int64_t ld);
+int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr);
+int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host);
+int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,
+                     double alpha, double beta);
+int slq_plan_fun_action_dmat(slq_plan *plan, int fun_id, const double *fun_params, slq_dmat *OUT, int o0);
 
 /* Device bandwidth probe with the access shape of the sweeps (16 B/lane, one contiguous window):
  * mode 0 = two read streams, 1 = in-place triad (2 reads + 1 write), 2 = copy. Reports GB/s. Used by

@@ -1406,6 +1406,139 @@ extern "C" int slq_diag_get(slq_diag *d, double *numer, double *denom, double *r
   return SLQ_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// tall-skinny device matrices (xtrace / hutch++ dense algebra on the matrix cores)
+// ---------------------------------------------------------------------------------------------------
+struct slq_dmat {
+  slq_context *ctx;
+  int64_t n;
+  int cols;
+  double *d;  // column-major, ld = n
+};
+
+extern "C" int slq_dmat_create(slq_context *ctx, int64_t n, int cols, slq_dmat **out) {
+  if (!ctx || !out || n <= 0 || cols <= 0) return fail(SLQ_EINVAL, "bad arguments");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  slq_dmat *m = new (std::nothrow) slq_dmat();
+  if (!m) return fail(SLQ_ENOMEM, "host allocation failed");
+  m->ctx = ctx; m->n = n; m->cols = cols; m->d = nullptr;
+  hipError_t e = hipMalloc((void **)&m->d, (size_t)n * cols * 8);
+  if (e == hipSuccess) e = hipMemsetAsync(m->d, 0, (size_t)n * cols * 8, ctx->stream);
+  if (e != hipSuccess) { delete m; return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "dmat: %s", hipGetErrorString(e)); }
+  *out = m;
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_destroy(slq_dmat *m) {
+  if (!m) return SLQ_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  if (m->d) hipFree(m->d);
+  delete m;
+  return SLQ_OK;
+}
+
+static int dmat_range(const slq_dmat *m, int c0, int nc, const char *what) {
+  if (!m) return fail(SLQ_EINVAL, "%s: matrix is NULL", what);
+  if (c0 < 0 || nc <= 0 || c0 + nc > m->cols) return fail(SLQ_EINVAL, "%s: columns [%d, %d) outside [0, %d)", what, c0, c0 + nc, m->cols);
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_set(slq_dmat *m, int c0, int nc, const double *host, int64_t ld) {
+  SLQ_TRY(dmat_range(m, c0, nc, "slq_dmat_set"));
+  if (!host || ld < m->n) return fail(SLQ_EINVAL, "bad host array");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy2DAsync(m->d + (size_t)c0 * m->n, (size_t)m->n * 8, host, (size_t)ld * 8, (size_t)m->n * 8, (size_t)nc,
+                           hipMemcpyHostToDevice, m->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_get(slq_dmat *m, int c0, int nc, double *host, int64_t ld) {
+  SLQ_TRY(dmat_range(m, c0, nc, "slq_dmat_get"));
+  if (!host || ld < m->n) return fail(SLQ_EINVAL, "bad host array");
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  HIP_TRY(hipMemcpy2DAsync(host, (size_t)ld * 8, m->d + (size_t)c0 * m->n, (size_t)m->n * 8, (size_t)m->n * 8, (size_t)nc,
+                           hipMemcpyDeviceToHost, m->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr) {
+  SLQ_TRY(dmat_range(m, c0, 1, "slq_dmat_ptr"));
+  if (!dptr) return fail(SLQ_EINVAL, "dptr is NULL");
+  *dptr = m->d + (size_t)c0 * m->n;
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host) {
+  SLQ_TRY(dmat_range(A, a0, ma, "slq_dmat_gemm_tn(A)"));
+  SLQ_TRY(dmat_range(B, b0, mb, "slq_dmat_gemm_tn(B)"));
+  if (!C_host || A->n != B->n || A->ctx != B->ctx) return fail(SLQ_EINVAL, "mismatched operands");
+  slq_context *ctx = A->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int n = (int)A->n;
+  const int tiles = ((ma + 16 * kTnA - 1) / (16 * kTnA)) * ((mb + 16 * kTnB - 1) / (16 * kTnB));
+  // enough single-wave workgroups to fill the chip: ~16 per CU
+  int nslab = std::max(1, std::min((n + 1023) / 1024, (ctx->num_cus * 16 + tiles - 1) / tiles));
+  int slab_rows = ((n + nslab - 1) / nslab + 15) / 16 * 16;
+  nslab = (n + slab_rows - 1) / slab_rows;
+  const size_t cnt = (size_t)ma * mb;
+  double *buf = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, ((size_t)nslab + 1) * cnt * 8));
+  k_gemm_tn<<<dim3(tiles, nslab), dim3(64), 0, st>>>(n, A->d + (size_t)a0 * n, (int64_t)n, B->d + (size_t)b0 * n, (int64_t)n, ma, mb,
+                                                    slab_rows, buf);
+  k_sum_slabs<<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(buf, nslab, (int64_t)cnt, buf + (size_t)nslab * cnt);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(C_host, buf + (size_t)nslab * cnt, cnt * 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(buf);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "slq_dmat_gemm_tn: %s", hipGetErrorString(e));
+  return SLQ_OK;
+}
+
+extern "C" int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,
+                                double alpha, double beta) {
+  SLQ_TRY(dmat_range(OUT, o0, mb, "slq_dmat_gemm_nn(OUT)"));
+  SLQ_TRY(dmat_range(A, a0, ma, "slq_dmat_gemm_nn(A)"));
+  if (!C_host || A->n != OUT->n || A->ctx != OUT->ctx) return fail(SLQ_EINVAL, "mismatched operands");
+  if (A == OUT && !(o0 + mb <= a0 || a0 + ma <= o0)) return fail(SLQ_EINVAL, "output columns overlap the input columns");
+  slq_context *ctx = A->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int n = (int)A->n;
+  double *dC = nullptr;
+  HIP_TRY(hipMalloc((void **)&dC, (size_t)ma * mb * 8));
+  hipError_t e = hipMemcpyAsync(dC, C_host, (size_t)ma * mb * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    k_gemm_nn<<<dim3((n + 15) / 16, (mb + 16 * kNnB - 1) / (16 * kNnB)), dim3(64), 0, st>>>(
+        n, OUT->d + (size_t)o0 * n, (int64_t)n, A->d + (size_t)a0 * n, (int64_t)n, ma, dC, mb, alpha, beta);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(dC);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "slq_dmat_gemm_nn: %s", hipGetErrorString(e));
+  return SLQ_OK;
+}
+
+// f(A) X for the probes of a completed keep_basis run, written to OUT[:, o0 : o0 + nprobes] (fp64 plans)
+extern "C" int slq_plan_fun_action_dmat(slq_plan *p, int fun_id, const double *fun_params, slq_dmat *OUT, int o0) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  SLQ_TRY(dmat_range(OUT, o0, p->nprobes, "slq_plan_fun_action_dmat"));
+  if (p->dtype != SLQ_F64 || OUT->n != p->n || OUT->ctx != p->ctx) return fail(SLQ_EINVAL, "plan and matrix do not match (fp64, same n, same context)");
+  SLQ_TRY(fun_action_device(p, fun_id, fun_params));
+  hipStream_t st = p->ctx->stream;
+  dim3 g((p->n + 63) / 64, (p->nprobes + 63) / 64);
+  hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, p->deg), 0, p->nprobes,
+                     OUT->d + (size_t)o0 * p->n, p->PW, (const double *)nullptr, p->op->perm_d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return SLQ_OK;
+}
+
 extern "C" int slq_measure_stream(slq_context *ctx, int mode, size_t bytes_per_stream, int reps, double *gbps) {
   if (!ctx || !gbps || mode < 0 || mode > 2 || reps < 1 || bytes_per_stream < (1u << 20))
     return fail(SLQ_EINVAL, "bad arguments");

@@ -1416,4 +1416,127 @@ __global__ __launch_bounds__(kBlock) void k_stream_probe(double *w, const double
   if (acc[0] + acc[1] == 1.234567e-300) sink[0] = acc[0];
 }
 
+
+// ---- tall-skinny dense algebra on the matrix cores (xtrace / hutch++ sketches) ----
+// Column-major n x m device matrices (n ~ 1e5..1e7, m <= a few hundred). Two products cover the
+// blocked Gram-Schmidt / CholeskyQR2 and the m x m summaries of XTrace:
+//   TN:  C (ma x mb) = A[:, a-range]^T B[:, b-range]          K = n: split into row slabs
+//   NN:  OUT[:, o-range] = beta*OUT + alpha * A[:, a-range] C  (C: ma x mb, row-major, small)
+// Both use v_mfma_f64_16x16x4_f64. In the TN kernel a lane loads 4 consecutive k for its column with
+// one 32-byte load and MFMA #s consumes element s: lane group g = lane>>4 then contributes
+// k = k0 + 4 g + s, the same for both operands, so every k in [k0, k0+16) is used exactly once and
+// each column contributes a full 128-byte line per load.
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTnA = 2;  // 16-column A fragments per wave (32 output rows)
+constexpr int kTnB = 4;  // 16-column B fragments per wave (64 output columns)
+
+__global__ __launch_bounds__(64) void k_gemm_tn(int n, const double *__restrict__ A, int64_t lda,
+                                                const double *__restrict__ B, int64_t ldb, int ma, int mb,
+                                                int slab_rows, double *__restrict__ partial /* [nslab][ma][mb] */) {
+  const int lane = threadIdx.x, lc = lane & 15, g = lane >> 4;
+  const int tiles_b = (mb + 16 * kTnB - 1) / (16 * kTnB);
+  const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
+  const int i0 = ta * 16 * kTnA, j0 = tb * 16 * kTnB;
+  const int slab = blockIdx.y;
+  const int k_begin = slab * slab_rows, k_end = min(n, k_begin + slab_rows);
+  d4v acc[kTnA][kTnB];
+#pragma unroll
+  for (int x = 0; x < kTnA; ++x)
+#pragma unroll
+    for (int y = 0; y < kTnB; ++y) acc[x][y] = (d4v)0.0;
+  for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+    const int k = k0 + 4 * g;
+    d4v a[kTnA], b[kTnB];
+#pragma unroll
+    for (int x = 0; x < kTnA; ++x) {
+      const int col = i0 + x * 16 + lc;
+      a[x] = (d4v)0.0;
+      if (col < ma) {
+        const double *p = A + (int64_t)col * lda + k;
+        if (k + 3 < k_end) a[x] = *(const d4v *)p;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < k_end) a[x][e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int y = 0; y < kTnB; ++y) {
+      const int col = j0 + y * 16 + lc;
+      b[y] = (d4v)0.0;
+      if (col < mb) {
+        const double *p = B + (int64_t)col * ldb + k;
+        if (k + 3 < k_end) b[y] = *(const d4v *)p;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < k_end) b[y][e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int x = 0; x < kTnA; ++x)
+#pragma unroll
+        for (int y = 0; y < kTnB; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x][e], b[y][e], acc[x][y], 0, 0, 0);
+  }
+  double *P = partial + (int64_t)slab * ma * mb;
+#pragma unroll
+  for (int x = 0; x < kTnA; ++x)
+#pragma unroll
+    for (int y = 0; y < kTnB; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + x * 16 + g + 4 * r, jj = j0 + y * 16 + lc;
+        if (i < ma && jj < mb) P[(int64_t)i * mb + jj] = acc[x][y][r];
+      }
+}
+
+__global__ void k_sum_slabs(const double *__restrict__ partial, int nslab, int64_t count, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int k = 0; k < nslab; ++k) s += partial[(int64_t)k * count + i];
+  out[i] = s;
+}
+
+constexpr int kNnB = 4;  // 16-column output fragments per wave
+
+__global__ __launch_bounds__(64) void k_gemm_nn(int n, double *OUT, int64_t ldo, const double *__restrict__ A,
+                                                int64_t lda, int ma, const double *__restrict__ C, int mb,
+                                                double alpha, double beta) {
+  const int lane = threadIdx.x, lc = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const int j0 = blockIdx.y * 16 * kNnB;
+  d4v acc[kNnB];
+#pragma unroll
+  for (int y = 0; y < kNnB; ++y) acc[y] = (d4v)0.0;
+  const bool row_ok = row0 + lc < n;
+  for (int k0 = 0; k0 < ma; k0 += 4) {
+    const int k = k0 + g;
+    const double a = (row_ok && k < ma) ? A[(int64_t)k * lda + row0 + lc] : 0.0;
+#pragma unroll
+    for (int y = 0; y < kNnB; ++y) {
+      const int col = j0 + y * 16 + lc;
+      const double b = (k < ma && col < mb) ? C[(int64_t)k * mb + col] : 0.0;
+      acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[y], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < kNnB; ++y) {
+    const int col = j0 + y * 16 + lc;
+    if (col >= mb) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + g + 4 * r;
+      if (row < n) {
+        double *o = OUT + (int64_t)col * ldo + row;
+        *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[y][r];
+      }
+    }
+  }
+}
+
 }  // namespace slq

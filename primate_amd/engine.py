@@ -249,6 +249,12 @@ class LanczosPlan:
 		check(_capi.lib().slq_plan_fun_action(self._h, fid, ptr(params), ptr(Y), Y.shape[0]))
 		return Y
 
+	def fun_action_into(self, out: "DeviceMatrix", o0: int, fun="identity", **fun_kwargs):
+		"""f(A) X of this run written straight into columns [o0, o0 + nprobes) of a DeviceMatrix."""
+		fid, params = fun_spec(fun, **fun_kwargs)
+		assert fid is not None
+		check(_capi.lib().slq_plan_fun_action_dmat(self._h, fid, ptr(params), out._h, int(o0)))
+
 	def basis(self, probe: int = 0) -> np.ndarray:
 		Q = np.zeros((self.op.shape[0], self.deg), dtype=self.op.dtype, order="F")
 		check(_capi.lib().slq_plan_get_basis(self._h, int(probe), ptr(Q), Q.shape[0]))
@@ -357,6 +363,56 @@ class DiagAccumulator:
 	def close(self):
 		if getattr(self, "_h", None):
 			_capi.lib().slq_diag_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self.close()
+		except Exception:  # noqa: BLE001
+			pass
+
+
+class DeviceMatrix:
+	"""Column-major n x cols fp64 matrix on the GPU with the two tall-skinny products of the
+	exchangeable estimators (slq_dmat_*: fp64 MFMA)."""
+
+	def __init__(self, n: int, cols: int, ctx: Optional[Context] = None):
+		self.ctx = ctx or default_context()
+		self.n, self.cols = int(n), int(cols)
+		h = C.c_void_p()
+		check(_capi.lib().slq_dmat_create(self.ctx._h, self.n, self.cols, C.byref(h)))
+		self._h = h
+
+	def set(self, c0: int, X: np.ndarray):
+		X = np.asfortranarray(np.asarray(X, dtype=np.float64).reshape(self.n, -1))
+		check(_capi.lib().slq_dmat_set(self._h, int(c0), X.shape[1], ptr(X), self.n))
+
+	def get(self, c0: int = 0, nc: Optional[int] = None) -> np.ndarray:
+		nc = self.cols - c0 if nc is None else int(nc)
+		X = np.empty((self.n, nc), order="F")
+		check(_capi.lib().slq_dmat_get(self._h, int(c0), nc, ptr(X), self.n))
+		return X
+
+	def col_ptr(self, c0: int) -> int:
+		p = C.c_void_p()
+		check(_capi.lib().slq_dmat_ptr(self._h, int(c0), C.byref(p)))
+		return p.value
+
+	def tn(self, a0: int, ma: int, B: "DeviceMatrix", b0: int, mb: int) -> np.ndarray:
+		"""self[:, a0:a0+ma].T @ B[:, b0:b0+mb]  (ma x mb, on the host)."""
+		out = np.zeros((ma, mb))
+		check(_capi.lib().slq_dmat_gemm_tn(self._h, int(a0), int(ma), B._h, int(b0), int(mb), ptr(out)))
+		return out
+
+	def add_product(self, o0: int, A: "DeviceMatrix", a0: int, Cm: np.ndarray, alpha: float = 1.0, beta: float = 1.0):
+		"""self[:, o0:o0+mb] = beta * self[:, o0:o0+mb] + alpha * A[:, a0:a0+ma] @ Cm."""
+		Cm = np.ascontiguousarray(Cm, dtype=np.float64)
+		ma, mb = Cm.shape
+		check(_capi.lib().slq_dmat_gemm_nn(self._h, int(o0), A._h, int(a0), ma, ptr(Cm), mb, float(alpha), float(beta)))
+
+	def close(self):
+		if getattr(self, "_h", None):
+			_capi.lib().slq_dmat_destroy(self._h)
 			self._h = None
 
 	def __del__(self):

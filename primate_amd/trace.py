@@ -130,27 +130,125 @@ def hutchpp(
 	return result.estimate, result
 
 
-def _xtrace(W: np.ndarray, Z: np.ndarray, Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf: str) -> np.ndarray:
-	"""Leave-one-out XTrace estimates for the m probes in W (Epperly, Tropp & Webber; the algebra of
-	src/primate/trace.py:185-227). Z = A Q, Q R = A W, R_inv = R^{-1}. Returns an (m, 1) column."""
+def _xtrace_small(n: int, Wq: np.ndarray, H: np.ndarray, T: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:
+	"""Leave-one-out XTrace estimates from the m x m summaries Wq = Q^T W, H = Q^T Z, T = Z^T W
+	(Epperly, Tropp & Webber; the algebra of src/primate/trace.py:199-227). Returns an (m, 1) column."""
 	cdot = lambda X, Y: np.einsum("ij,ij->j", X, Y)[:, None]  # noqa: E731  column-wise dot products
-	n, m = W.shape
-	Wq = Q.T @ W
+	m = Wq.shape[0]
 	S = R_inv.T / np.linalg.norm(R_inv, axis=1)
 	if pdf != "sphere":
 		scale = np.ones((m, 1))
 	else:
 		c = n - m + 1
 		scale = c / (n - np.linalg.norm(Wq, axis=0)[:, None] ** 2 + (cdot(S, Wq) * np.linalg.norm(S, axis=0)[:, None]) ** 2)
-	H = Q.T @ Z
 	HW = H @ Wq
-	T = Z.T @ W
 	dSW, dSHS = cdot(S, Wq), cdot(S, H @ S)
 	dTW, dWHW = cdot(T, Wq), cdot(Wq, HW)
 	dSRmHW, dTmHRS = cdot(S, R - HW), cdot(T - H.T @ Wq, S)
 	ests = np.trace(H) * np.ones((m, 1)) - dSHS
 	ests += (-dTW + dWHW + dSW * dSRmHW + np.abs(dSW) ** 2 * dSHS + dTmHRS * dSW) * scale
 	return ests
+
+
+def _xtrace(W: np.ndarray, Z: np.ndarray, Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:
+	"""XTrace estimates for the m probes in W; Z = A Q, Q R = A W, R_inv = R^{-1} (trace.py:185-227)."""
+	return _xtrace_small(W.shape[0], Q.T @ W, Q.T @ Z, Z.T @ W, R, R_inv, pdf)
+
+
+def _qr_append_block(Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, Y: np.ndarray) -> tuple:
+	"""QR factors of [Q R, Y] from those of Q R, a whole block at a time.
+
+	The reference appends the ns new columns one by one with scipy's `qr_insert` (Givens, BLAS-2:
+	O(n m) memory traffic per column, trace.py:298-300). Here the block is orthogonalised against Q
+	with two classical Gram-Schmidt passes (BLAS-3) and factored on its own; R and R^{-1} grow by a
+	block column. The factorisation is the same up to the signs of R's diagonal, to which the XTrace
+	estimates are invariant (every term of `_xtrace` pairs a column of Q or S with itself)."""
+	m, ns = Q.shape[1], Y.shape[1]
+	C = np.zeros((m, ns))
+	for _ in range(2):  # "twice is enough"
+		Ci = Q.T @ Y
+		Y = Y - Q @ Ci
+		C += Ci
+	Qn, Rn = np.linalg.qr(Y, mode="reduced")
+	R_new = np.zeros((m + ns, m + ns))
+	R_new[:m, :m], R_new[:m, m:], R_new[m:, m:] = R, C, Rn
+	from scipy.linalg import solve_triangular
+
+	Rn_inv = solve_triangular(Rn, np.eye(ns))
+	Ri_new = np.zeros((m + ns, m + ns))
+	Ri_new[:m, :m], Ri_new[m:, m:] = R_inv, Rn_inv
+	Ri_new[:m, m:] = -R_inv @ C @ Rn_inv
+	return np.c_[Q, Qn], R_new, Ri_new
+
+
+def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, callback: Callable, result: EstimatorResult):
+	"""xtrace for a device `MatrixFunction` with everything n-sized resident on the GPU: the sketches
+	W, Q, Z are column-major device matrices; f(A)·(new probes) and f(A)·(new Q columns) are lock-step
+	Lanczos batches whose outputs never leave HBM; the block Gram-Schmidt + CholeskyQR2 and the
+	three m x m summaries are fp64 MFMA products (slq_dmat_gemm_tn / _nn). Only m x m matrices and the
+	host-drawn probes cross PCIe. Same estimator as the host path (sign-of-R invariance as in
+	`_qr_append_block`)."""
+	from scipy.linalg import cholesky, solve_triangular
+
+	from . import engine
+
+	n = A.shape[0]
+	name, kw = A._builtin
+	ctx = A._op.ctx
+	P = min(budget, n)
+	Wd, Qd, Zd = (engine.DeviceMatrix(n, P, ctx=ctx) for _ in range(3))
+	Yd, Td = engine.DeviceMatrix(n, batch, ctx=ctx), engine.DeviceMatrix(n, batch, ctx=ctx)
+	R, R_inv = np.zeros((0, 0)), np.zeros((0, 0))
+	estimator = MeanEstimator(record=record)
+	m = 0
+
+	def apply_fun(src: "engine.DeviceMatrix", c0: int, ns: int, dst: "engine.DeviceMatrix", o0: int):
+		plan = A._plan(ns, True)
+		plan.set_probes_device(src.col_ptr(c0))
+		plan.run(A._rtol)
+		plan.fun_action_into(dst, o0, name, **kw)
+
+	try:
+		while m < P:
+			ns = min(int(batch), P - m)
+			Wd.set(m, draw(size=(n, ns)))
+			apply_fun(Wd, m, ns, Yd, 0)
+			## block Gram-Schmidt against the existing Q, twice
+			Cm = np.zeros((m, ns))
+			if m > 0:
+				for _ in range(2):
+					Ci = Qd.tn(0, m, Yd, 0, ns)
+					Yd.add_product(0, Qd, 0, Ci, alpha=-1.0, beta=1.0)
+					Cm += Ci
+			## CholeskyQR2 of the remainder: Y -> T = Y R1^{-1} -> Q_new = T R2^{-1}; R_n = R2 R1
+			try:
+				R1 = cholesky(Yd.tn(0, ns, Yd, 0, ns), lower=False)
+				Td.add_product(0, Yd, 0, solve_triangular(R1, np.eye(ns)), alpha=1.0, beta=0.0)
+				R2 = cholesky(Td.tn(0, ns, Td, 0, ns), lower=False)
+				Qd.add_product(m, Td, 0, solve_triangular(R2, np.eye(ns)), alpha=1.0, beta=0.0)
+				Rn = R2 @ R1
+			except np.linalg.LinAlgError:
+				## numerically rank-deficient block: Householder QR of this block on the host
+				Qn, Rn = np.linalg.qr(Yd.get(0, ns), mode="reduced")
+				Qd.set(m, Qn)
+			R_new = np.zeros((m + ns, m + ns))
+			R_new[:m, :m], R_new[:m, m:], R_new[m:, m:] = R, Cm, Rn
+			Rn_inv = solve_triangular(Rn, np.eye(ns))
+			Ri_new = np.zeros((m + ns, m + ns))
+			Ri_new[:m, :m], Ri_new[m:, m:] = R_inv, Rn_inv
+			Ri_new[:m, m:] = -R_inv @ Cm @ Rn_inv
+			R, R_inv = R_new, Ri_new
+			apply_fun(Qd, m, ns, Zd, m)
+			m += ns
+			t_samples = _xtrace_small(n, Qd.tn(0, m, Wd, 0, m), Qd.tn(0, m, Zd, 0, m), Zd.tn(0, m, Wd, 0, m), R, R_inv, None)
+			estimator = MeanEstimator(record=record)
+			estimator.update(t_samples.ravel())
+			result.estimator, result.estimate, result.nit = estimator, estimator.estimate, m
+			callback(result)
+	finally:
+		for d in (Wd, Qd, Zd, Yd, Td):
+			d.close()
+	return result
 
 
 def xtrace(
@@ -172,8 +270,6 @@ def xtrace(
 	too; pass `count=` (extra keyword) to stop after that many probes instead (BASELINE.json
 	configs[2] uses 512).
 	"""
-	from scipy.linalg import qr_insert
-
 	assert batch >= 1, "Batch size must be positive."
 	n = A.shape[0]
 	callback = (lambda result: ...) if not callable(callback) else callback
@@ -192,13 +288,20 @@ def xtrace(
 	## (trace.py:295 then :305), so its `pdf == "sphere"` test (trace.py:207) is never true and the
 	## sphere rescaling is never applied. Same here: results match the reference for every pdf.
 	pdf_name = None
+	from .operators import MatrixFunction
+
+	if (
+		isinstance(A, MatrixFunction) and A._builtin is not None and A.dtype == np.float64 and not A._stale_ring
+		and kwargs.pop("device", True)
+	):  # fmt: skip
+		_xtrace_device(A, batch, draw, stop.count, record, callback, result)
+		result.criterion = stop
+		return (result.estimate, result) if full else result.estimate
 	while not stop(estimator):
 		ns = min(A.shape[1] - W.shape[1], int(batch), stop.count - W.shape[1])
 		Nw = draw(size=(n, ns))
 		Y = np.asarray(A @ Nw)
-		for j in range(ns):
-			Q, R = qr_insert(Q, R, u=Y[:, j], k=Q.shape[1], which="col")
-			R_inv = update_trinv(R_inv, R[:, -1])
+		Q, R, R_inv = _qr_append_block(Q, R, R_inv, Y)
 		W = np.c_[W, Nw]
 		Z = np.c_[Z, np.asarray(A @ Q[:, -ns:])]
 		t_samples = _xtrace(W, Z, Q, R, R_inv, pdf_name)

@@ -89,5 +89,25 @@ if "c5" in which:
     dt = time.time() - t0
     out["c5"] = dict(n=n, nnz=int(A.nnz), k=k, probes=P, orth=k, seconds=dt, probe_matvecs_per_s=P * k / dt, eigencount=float(q.mean()), stderr=float(q.std(ddof=1) / np.sqrt(P)))
     print(json.dumps({"c5": out["c5"]}), flush=True)
+
+if "c3x" in which:
+    # config 3 as written: xtrace of exp(A), G(n, 16/n), n = 5e5, k = 40, 512 probes in batches of 128
+    from primate_amd.operators import MatrixFunction
+    from primate_amd.trace import xtrace, hutch
+    n, k, P = 500000, 40, int(os.environ.get("C3_PROBES", 512))
+    rng = np.random.default_rng(1234)
+    mm = int(n * 16 / 2)
+    i, j = rng.integers(0, n, mm), rng.integers(0, n, mm)
+    keep = i != j
+    W = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(n, n)).tocsr()
+    W = ((W + W.T) > 0).astype(np.float64).tocsr(); W.sort_indices()
+    M = MatrixFunction(W, fun="exp", deg=k, orth=3)
+    t0 = time.time(); marks = []
+    est, info = xtrace(M, batch=128, seed=1234, count=P, full=True, callback=lambda r: marks.append((r.nit, float(r.estimate), time.time() - t0)))
+    dt = time.time() - t0
+    t0 = time.time(); h = hutch(M, converge="count", count=P, seed=1234); dth = time.time() - t0
+    out["c3x"] = dict(n=n, nnz=int(W.nnz), k=k, probes=P, xtrace_seconds=dt, xtrace_estimate=float(est), progress=marks, hutch_seconds=dth, hutch_estimate=float(h))
+    print(json.dumps({"c3x": out["c3x"]}), flush=True)
+
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 json.dump(out, open(ROOT / "gpurun_out" / ("configs_" + "_".join(which) + ".json"), "w"), indent=1)

@@ -469,3 +469,25 @@ def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 		for o in (0, 3):
 			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[:6], ref[o], rtol=1e-10)
 		op.close()
+
+
+def test_tall_skinny_mfma_products(eng):
+	"""slq_dmat_gemm_tn / _nn (fp64 MFMA) against NumPy, ragged sizes on every edge."""
+	rng = np.random.default_rng(0)
+	for n, ma, mb in [(1000, 16, 16), (4099, 37, 70), (20011, 130, 5), (517, 3, 129)]:
+		A, B = rng.standard_normal((n, ma)), rng.standard_normal((n, mb))
+		dA, dB = eng.DeviceMatrix(n, ma + 2), eng.DeviceMatrix(n, mb + 3)
+		dA.set(1, A)
+		dB.set(2, B)
+		np.testing.assert_allclose(dA.get(1, ma), A)
+		C = dA.tn(1, ma, dB, 2, mb)
+		np.testing.assert_allclose(C, A.T @ B, rtol=1e-12, atol=1e-10)
+		M = rng.standard_normal((ma, mb))
+		dB.add_product(2, dA, 1, M, alpha=-0.5, beta=1.0)
+		np.testing.assert_allclose(dB.get(2, mb), B - 0.5 * A @ M, rtol=1e-12, atol=1e-11)
+		dB.add_product(2, dA, 1, M, alpha=2.0, beta=0.0)
+		np.testing.assert_allclose(dB.get(2, mb), 2.0 * A @ M, rtol=1e-12, atol=1e-11)
+		assert np.all(dB.get(0, 2) == 0) and np.all(dA.get(0, 1) == 0)  # neighbours untouched
+		with pytest.raises(ValueError):
+			dA.add_product(0, dA, 1, np.zeros((ma, 3)))  # overlapping in/out columns
+		dA.close(), dB.close()
