@@ -115,6 +115,7 @@ def main():
 	ap.add_argument("--probes", type=int, default=256, help="probes per GPU")
 	ap.add_argument("--workload", default="lap2d_1000", help="lap2d_<m> | lap3d_<m>")
 	ap.add_argument("--fun", default="log")
+	ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="arithmetic type of the operator and the Lanczos vectors")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--cpu-seconds", type=float, default=15.0)
 	args = ap.parse_args()
@@ -148,8 +149,9 @@ def main():
 	from primate_amd.engine import Context, DeviceOperator, LanczosPlan
 
 	kind, m = args.workload.split("_")
-	A = laplacian_2d(int(m)) if kind == "lap2d" else laplacian_3d(int(m))
-	n, nnz, s = A.shape[0], A.nnz, 8
+	np_dt = np.float64 if args.dtype == "f64" else np.float32
+	A = laplacian_2d(int(m), dtype=np_dt) if kind == "lap2d" else laplacian_3d(int(m), dtype=np_dt)
+	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
 	ctx = Context(device=local_rank)
 	op = DeviceOperator(A, ctx=ctx)  # CSR resident in HBM before the timed region
 	P, deg = args.probes, min(args.deg, n)
@@ -203,7 +205,8 @@ def main():
 	ms_per_step = elapsed / args.steps * 1e3
 
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
-	pw = 128 if P > 64 else (64 if P > 32 else (32 if P > 16 else 16))
+	vlen = 16 // s  # probes per lane (16-byte loads)
+	pw = next(l * vlen for l in (8, 16, 32, 64) if l * vlen >= P or l == 64)
 	fused = os.environ.get("SLQ_FUSED", "1") != "0"
 	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, fused=fused)
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
@@ -244,9 +247,9 @@ def main():
 	line = {
 		"metric": "probe-matvecs/sec", "value": round(value, 1), "unit": "probe-matvecs/s", "n_gpus": world,
 		"steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-		"scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+		"scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
 		"config": {
-			"workload": f"configs[1]: logdet via SLQ, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={args.fun}",
+			"workload": f"{'configs[1]: logdet via SLQ' if args.workload == 'lap2d_1000' and args.dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={args.fun}",
 			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
 			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused),
 		},

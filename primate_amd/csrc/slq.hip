@@ -355,15 +355,51 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
   std::vector<int32_t> rp2, ci2;
   std::vector<char> va2;
-  // OFF by default: on the 2-D grid of configs[1] it RAISED the alpha pass's fetch traffic from 6.5 to
-  // 8.9 GB per launch and its time from 0.97 to 1.20 ms — kept as an opt-in experiment
-  // (SLQ_REORDER=1: operators with n >= 65536; =2: all) so the permuted-row plumbing stays tested.
-  const int reorder_mode = env_int("SLQ_REORDER", 0);
-  if (reorder_mode != 0 && (n >= 65536 || reorder_mode == 2) && nnz > 0) {
+  // SLQ_REORDER: 0 never, 1 operators with n >= 65536, 2 always, unset = automatic. Measured (DESIGN.md
+  // §5.3): on the 2-D grid of configs[1] (rms |i-j| of the nonzeros = 632 rows) it RAISED the alpha pass's
+  // fetch traffic from 6.5 to 8.9 GB and the step time by 10 %; on 3-D grids (100^3: rms |i-j| = 5345,
+  // 126^3: 8486) whose natural-order halo no longer fits any cache level it is 9-12 % FASTER. Automatic
+  // mode therefore reorders only when the rms index distance exceeds 2048 rows AND the permutation cuts
+  // it to 60 % or less (random graphs gain nothing and are left alone).
+  const int reorder_mode = env_int("SLQ_REORDER", -1);
+  // rms index distance of the nonzeros whose two ends lie in the same XCD chunk (links that cross
+  // chunks are served by another XCD's L2 whatever the order inside the chunks)
+  const int64_t rchunk = (n + 7) / 8;
+  auto mean_dist = [&](const std::vector<int32_t> *inv) {
+    double acc = 0.0;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t ii = inv ? (*inv)[(size_t)i] : i;
+      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+        if (colind[q] / rchunk != i / rchunk) continue;
+        const int64_t jj = inv ? (*inv)[(size_t)colind[q]] : colind[q];
+        const double dd = (double)(ii > jj ? ii - jj : jj - ii);
+        acc += dd * dd;
+        ++cnt;
+      }
+    }
+    return std::sqrt(acc / (double)std::max<int64_t>(cnt, 1));
+  };
+  bool want = false;
+  if (nnz > 0) {
+    if (reorder_mode == 2) want = true;
+    else if (reorder_mode == 1) want = n >= 65536;
+    else if (reorder_mode < 0) want = n >= 65536 && mean_dist(nullptr) > 2048.0;
+  }
+  if (want) {
     op->perm_h = new (std::nothrow) std::vector<int32_t>();
     if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
     std::vector<int32_t> &perm = *op->perm_h;
     xcd_rcm_permutation(n, rowptr, colind, perm);
+    std::vector<int32_t> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+    if (reorder_mode < 0 && mean_dist(&inv) > 0.6 * mean_dist(nullptr)) {
+      delete op->perm_h;  // no locality to gain: keep the caller's order
+      op->perm_h = nullptr;
+    }
+  }
+  if (op->perm_h) {
+    std::vector<int32_t> &perm = *op->perm_h;
     std::vector<int32_t> inv((size_t)n);
     for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
     rp2.resize((size_t)n + 1);
