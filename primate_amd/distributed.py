@@ -100,3 +100,37 @@ def sharded_hutch_device(op, nprobes: int, deg: int, orth: int, fun="identity", 
 	if world == 1:
 		return merge_statistics(local_statistics(q))
 	return allreduce_trace(q, group=group)
+
+
+def sharded_diag_device(op, nprobes: int, deg: int, orth: int = 3, fun="identity", pdf: str = "rademacher", seed: int = 0, rtol: float = 1e-8, batch: int = 256, group=None, **fun_kwargs):
+	"""diag f(A) with a fixed probe budget sharded over the ranks of `group` (BASELINE.json configs[3]):
+	every rank accumulates numer += f(A)v * v and denom += v * v on its own GPU for its probe ids, then
+	ONE all-reduce of the 2n-vector (numer, denom) combines them (16 MB at n = 2e6 fp32).
+	Returns (numer / denom, numer, denom, count) — the Hutchinson diagonal estimate of the pooled probes.
+	(The reference's running mean of successive ratios, diagonal.py:79, is order-dependent and is only
+	reproduced by the single-process `primate_amd.diagonal.diag`.)"""
+	import torch.distributed as dist
+
+	from .engine import DiagAccumulator, LanczosPlan
+
+	rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+	lo, hi = shard_range(nprobes, rank, world)
+	n = op.shape[0]
+	acc = DiagAccumulator(n, ctx=op.ctx)
+	done = lo
+	while done < hi:
+		m = min(batch, hi - done)
+		plan = LanczosPlan(op, m, deg, orth, keep_basis=True)
+		plan.generate_probes(pdf, seed=seed, probe_offset=done)
+		plan.run(rtol)
+		acc.update(plan, fun, **fun_kwargs)
+		plan.close()
+		done += m
+	numer, denom, _, cnt = acc.get()
+	acc.close()
+	if world > 1:
+		both = allreduce_sum(np.concatenate([numer, denom, [float(cnt)]]), group=group)
+		numer, denom, cnt = both[:n], both[n : 2 * n], int(round(both[-1]))
+	with np.errstate(divide="ignore", invalid="ignore"):
+		est = numer / denom
+	return est, numer, denom, cnt

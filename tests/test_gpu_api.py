@@ -255,3 +255,22 @@ def test_stale_ring_compat_reproduces_reference_quad(oracle, golden):
 		assert s1 == s2
 		np.testing.assert_allclose(al, al2, rtol=tol, atol=tol)
 		np.testing.assert_allclose(be, be2, rtol=tol, atol=tol)
+
+
+def test_sharded_drivers_single_rank(golden):
+	"""The probe-sharded drivers on one rank (world = 1): same per-probe streams as one big batch."""
+	from primate_amd.distributed import sharded_diag_device, sharded_hutch_device
+	from primate_amd.engine import DeviceOperator, LanczosPlan
+
+	L = laplacian_2d(30)
+	op = DeviceOperator(L)
+	cnt, mean, var = sharded_hutch_device(op, 96, 20, 3, fun="log", seed=5)
+	plan = LanczosPlan(op, 96, 20, 3)
+	plan.generate_probes("rademacher", seed=5)
+	plan.run()
+	q = plan.quadrature("log")
+	assert cnt == 96 and mean == pytest.approx(q.mean(), rel=1e-13) and var == pytest.approx(q.var(ddof=1), rel=1e-10)
+	est, numer, denom, c = sharded_diag_device(op, 40, 20, 20, fun="exp", t=-0.1, seed=5, batch=16)
+	ew, ev = np.linalg.eigh(L.toarray())
+	exact = np.einsum("ij,j,ij->i", ev, np.exp(-0.1 * ew), ev)
+	assert c == 40 and np.all(denom == 40) and np.linalg.norm(est - exact) / np.linalg.norm(exact) < 0.15
