@@ -75,6 +75,11 @@ struct slq_operator {
   int32_t *perm_d;               // device: stored row i = caller row perm[i]; null if not reordered
   std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
   RowTiles tiles;                // LDS row tiles for the wide-panel fused passes (tile_ptr == null: none)
+  // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
+  // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
+  int32_t *rowptr_u = nullptr, *colind_u = nullptr;
+  void *vals_u = nullptr;
+  double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
 };
 
 struct ProfEvent {
@@ -96,7 +101,8 @@ struct slq_plan {
   StepState st;
   double *scal;         // one allocation behind all StepState arrays
   double *part;
-  int nblkA, nblkS, nblkU, nblkT;  // grids: SpMM/alpha pass, streaming sweeps, fused dots/update passes, tiled passes
+  int nblkA, nblkS, nblkU, nblkT;  // grids: SpMM, streaming sweeps, fused dots/update passes, tiled passes
+  int nblkF;                       // grid of the fused alpha pass
   double *quad_d, *nodes_d, *weights_d;
   int *fail_d;
   int rmax;
@@ -330,6 +336,46 @@ static bool build_row_tiles(int64_t n, const int32_t *rowptr, const int32_t *col
   return false;
 }
 
+// If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
+// upper entries doubled and return true. One pass with a per-row cursor: rows are visited in ascending i,
+// so the lower entries (j, i) of row j are met in the order they are stored.
+template <typename F>
+static bool build_symmetric_upper(int64_t n, const int32_t *rowptr, const int32_t *colind, const F *vals,
+                                  std::vector<int32_t> &urp, std::vector<int32_t> &uci, std::vector<char> &uva) {
+  std::vector<int32_t> cur(rowptr, rowptr + n);
+  urp.assign((size_t)n + 1, 0);
+  size_t nu = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      const int32_t j = colind[q];
+      if (q > rowptr[i] && colind[q - 1] >= j) return false;  // unsorted or duplicate
+      if (j >= i) ++nu;
+      if (j > i) {
+        const int32_t c = cur[(size_t)j];
+        if (c >= rowptr[j + 1] || colind[c] != (int32_t)i || !(vals[c] == vals[q])) return false;
+        cur[(size_t)j] = c + 1;
+      }
+    }
+  }
+  for (int64_t j = 0; j < n; ++j)   // every lower entry must have been claimed by its mirror
+    if (cur[(size_t)j] < rowptr[j + 1] && colind[cur[(size_t)j]] < j) return false;
+  uci.resize(nu);
+  uva.resize(nu * sizeof(F));
+  F *uv = (F *)uva.data();
+  size_t w = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      const int32_t j = colind[q];
+      if (j < i) continue;
+      uci[w] = j;
+      uv[w] = j == i ? vals[q] : (F)2 * vals[q];
+      ++w;
+    }
+    urp[(size_t)i + 1] = (int32_t)w;
+  }
+  return true;
+}
+
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
                               slq_operator **out) {
@@ -393,11 +439,15 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     xcd_rcm_permutation(n, rowptr, colind, perm);
     std::vector<int32_t> inv((size_t)n);
     for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
-    if (reorder_mode < 0 && mean_dist(&inv) > 0.6 * mean_dist(nullptr)) {
+    const double d_new = mean_dist(&inv);
+    if (reorder_mode < 0 && d_new > 0.6 * mean_dist(nullptr)) {
       delete op->perm_h;  // no locality to gain: keep the caller's order
       op->perm_h = nullptr;
+    } else {
+      op->rms_dist = d_new;
     }
   }
+  if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
   if (op->perm_h) {
     std::vector<int32_t> &perm = *op->perm_h;
     std::vector<int32_t> inv((size_t)n);
@@ -437,6 +487,30 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   if (e != hipSuccess) {
     slq_operator_destroy(op);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
+  }
+  // Symmetric operators (what Lanczos assumes; the reference never checks): the alpha pass only needs the
+  // scalar q^T A q, so it can run on the upper triangle with doubled off-diagonals and gather half the
+  // panel rows. Built only when the stored CSR is EXACTLY symmetric (pattern and values, sorted rows
+  // without duplicates); anything else keeps the full rows. SLQ_SYM_ALPHA=0 disables it.
+  if (env_int("SLQ_SYM_ALPHA", 1) != 0 && nnz > 0) {
+    std::vector<int32_t> urp, uci;
+    std::vector<char> uva;
+    bool sym = dtype == SLQ_F64 ? build_symmetric_upper<double>(n, rowptr, colind, (const double *)vals, urp, uci, uva)
+                                : build_symmetric_upper<float>(n, rowptr, colind, (const float *)vals, urp, uci, uva);
+    if (sym) {
+      const size_t nu = uci.size();
+      hipError_t ue = hipMalloc((void **)&op->rowptr_u, (size_t)(n + 1) * 4);
+      if (ue == hipSuccess) ue = hipMalloc((void **)&op->colind_u, std::max<size_t>(nu * 4, 4));
+      if (ue == hipSuccess) ue = hipMalloc(&op->vals_u, std::max<size_t>(nu * es, 8));
+      if (ue == hipSuccess) ue = hipMemcpyAsync(op->rowptr_u, urp.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+      if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->colind_u, uci.data(), nu * 4, hipMemcpyHostToDevice, ctx->stream);
+      if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->vals_u, uva.data(), nu * es, hipMemcpyHostToDevice, ctx->stream);
+      if (ue == hipSuccess) ue = hipStreamSynchronize(ctx->stream);
+      if (ue != hipSuccess) {
+        slq_operator_destroy(op);
+        return fail(ue == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "upper-triangle upload: %s", hipGetErrorString(ue));
+      }
+    }
   }
   // LDS row tiles (wide-panel fused passes). EXPERIMENTAL, off by default: measured 1.7x SLOWER than the
   // generic passes on configs[1] (1.6 vs 0.93 ms for the alpha pass): the 1-KiB-row LDS
@@ -534,6 +608,9 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   }
   if (op->perm_d) hipFree(op->perm_d);
   delete op->perm_h;
+  if (op->rowptr_u) hipFree(op->rowptr_u);
+  if (op->colind_u) hipFree(op->colind_u);
+  if (op->vals_u) hipFree(op->vals_u);
   if (op->tiles.tile_ptr) {
     hipFree((void *)op->tiles.tile_ptr);
     hipFree((void *)op->tiles.tile_cols);
@@ -754,6 +831,18 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
   {
+    // Fused alpha pass: one read sweep plus the gathers, latency-bound at 2 workgroups per CU. With the
+    // halo of the in-flight rows inside the XCD's L2 (2-D grid: rms in-chunk |i-j| = 632) 4 per CU is 25 %
+    // faster (0.88 -> 0.5 ms on configs[1]); on 3-D grids (rms > 1024 even after reordering) and random
+    // graphs the extra rows in flight evict each other's halo and 2 per CU stays best.
+    const int local = op->kind == OP_CSR && op->rms_dist >= 0.0 && op->rms_dist <= 1024.0;
+    const int per_cu_f = std::max(1, env_int("SLQ_BLOCKS_PER_CU_ALPHA", local ? 4 : 2));
+    const int rows_per_block = kWaves * (64 / p->LPR);
+    const int chunk = (p->n + 7) / 8;
+    const int per_xcd = std::min(std::max(8, ctx->num_cus * per_cu_f / p->NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
+    p->nblkF = 8 * std::max(per_xcd, 1);
+  }
+  {
     // tiled passes: 1 workgroup per CU resident (8 wave-private LDS images), one panel at a time
     const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", 1));
     int per_xcd_t = std::max(1, ctx->num_cus * per_cu_t / 8);
@@ -766,8 +855,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t ring_bytes = (size_t)p->S * (size_t)p->slot_stride * p->esz;
   const size_t bp = p->bpad;
   // alpha[deg+1], nu[orth margin for stale vectors t < 0 | deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
-  const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + (size_t)p->rmax) * bp;
-  const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(p->nblkA, p->nblkU), p->nblkS), p->nblkT) * bp;
+  const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + 1 + (size_t)p->rmax) * bp;
+  const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
@@ -787,6 +876,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->st.vnorm2 = s; s += bp;
   p->st.coefA = s; s += 2 * bp;
   p->st.coefB = s; s += bp;
+  p->st.cross = s; s += bp;
   p->st.gamma = s;
   p->st.steps = p->st.active + bp;
   p->fail_d = p->st.steps + bp;
@@ -962,7 +1052,7 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
   const slq_operator *op = p->op;
   hipStream_t st = p->ctx->stream;
   const int nblk = (p->n + 15) / 16;
-  if ((size_t)nblk > (size_t)kReorthChunk * std::max(std::max(std::max(p->nblkA, p->nblkU), p->nblkS), p->nblkT))
+  if ((size_t)nblk > (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT))
     return fail(SLQ_EINVAL, "dense operator too large for the partials buffer");
   const dim3 g(nblk, p->NP);
 #define DENSE_LAUNCH(TWV, COL0)                                                                             \
@@ -1044,8 +1134,10 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
   HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
   const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gU(p->nblkU, p->NP), gF((bp + 63) / 64);
+  const dim3 gAf(p->nblkF, p->NP);
   const dim3 gT(p->nblkT, p->NP);
   const slq_operator *op = p->op;
+  bool prev_xt = false;  // the previous step's update pass produced the cross term W_{j}.W_{j-1}
   for (int j = 0; j < deg; ++j) {
     const int sc_ = j % S, sp_ = (j + S - 1) % S, sn_ = (j + 1) % S;
     const int first = (j == 0);
@@ -1061,11 +1153,10 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
-      const int fused_alpha_pad = 65536;
       // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
       const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0;
       const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
-#define CSR_PASS(PASS, LP, SP, I0, RC, LDS)                                                          \
+#define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
   do {                                                                                               \
     if (tiled) {                                                                                     \
       if (p->dtype == SLQ_F64)                                                                       \
@@ -1077,31 +1168,37 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
             p->n, op->rowptr, (const float *)op->vals, op->tiles, (float *)p->ring, p->slot_stride, S, \
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
     } else {                                                                                         \
+      const bool half = PASS == PASS_ALPHA && op->rowptr_u != nullptr;                               \
       DISPATCH(p->dtype, p->LPR,                                                                     \
-               (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gA : gU), dim3(kBlock), LDS, st>>>( \
-                   p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, S, \
-                   j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp))); \
+               (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gAf : gU), dim3(kBlock), LDS, st>>>( \
+                   p->n, half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,         \
+                   (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S,       \
+                   j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp, XT))); \
     }                                                                                                \
   } while (0)
-      // alpha pass: its 58 VGPRs would admit 4 workgroups per CU; 2 resident ones (64 KiB of LDS padding)
-      // keep the rows in flight per XCD at 512 and the panels strictly one after the other, which
-      // measured 4-5 % faster than 4 per CU (0.92 vs 0.96 ms) and fetches less
-      const size_t ldsA = lds0 + (tiled ? 0 : (size_t)env_int("SLQ_ALPHA_LDS_PAD", fused_alpha_pad));
-      PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA); });
+      // alpha pass: residency is set by its grid (nblkF, slq_plan_create); SLQ_ALPHA_LDS_PAD can cap it
+      // further with LDS padding (experiments)
+      const size_t ldsA = lds0 + (tiled ? 0 : (size_t)env_int("SLQ_ALPHA_LDS_PAD", 0));
+      // cross term: the update pass of the previous step left W_c.W_p behind, so this alpha pass skips W_p
+      const int xt_a = (prev_xt && j > 0) ? 1 : 0;
+      const int xt_u = (!tiled && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0;
+      PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xt_a); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xt_a); });
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkA, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkF, j, xt_a));
       if (r > 0) {
-        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0); });
+        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0, 0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0, 0); });
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
                                     p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
       }
       const size_t ldsU = lds0 + (size_t)r * p->PW * p->esz;
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
-               { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU); });
+               { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_u); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_u); });
 #undef CSR_PASS
       nblk_last = tiled ? p->nblkT : p->nblkU;
+      prev_xt = xt_u != 0;
     } else {
+    prev_xt = false;
     if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
 #define SPMM_LAUNCH(LP, SP)                                                                          \
@@ -1121,12 +1218,12 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       });
 #undef SPMM_LAUNCH
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j, 0));
     } else if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && env_int("SLQ_DENSE_MFMA", 1) != 0) {
       int nb = 0;
       PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, sc_), slot_ptr(p, sp_), slot_ptr(p, sn_), first, 0, &nb)));
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, nb, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, nb, j, 0));
     } else {
       SLQ_TRY(apply_operator_unfused(p, sc_));
       PROFILED(p, SLQ_K_AXPY_NORM,
@@ -1136,7 +1233,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
                                             (const F *)slot_ptr(p, sp_), (F *)slot_ptr(p, sn_),
                                             p->st.coefA, p->part, bp, first))));
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkS, j, 0));
     }
     if (r == 0) {
       PROFILED(p, SLQ_K_AXPY_NORM,
@@ -1172,7 +1269,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
     }
     }  // !fused
     PROFILED(p, SLQ_K_FINALIZE,
-             hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, nblk_last, j, residual_tol));
+             hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, nblk_last, j, residual_tol, prev_xt ? 1 : 0));
   }
   HIP_TRY(hipGetLastError());
   return SLQ_OK;

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
     const F *__restrict__ vals, F *ring, int64_t slot_stride, int S, int j, int i0, int rc,
     const double *__restrict__ coefA, const double *__restrict__ coefB,
     const double *__restrict__ gamma /* PASS_UPDATE: [rc][bpad] */, double *__restrict__ part,
-    int bpad) {
+    int bpad, int xt) {
+  // xt (cross term): PASS_UPDATE also reduces X = sum_i w_{j+1}[i] w_j[i] into the second partial slab,
+  // and the NEXT step's PASS_ALPHA then leaves W_p unread: alpha = q_c.(A q_c) - beta (q_c.q_p) with the
+  // second dot taken from X (k_fin_alpha) - one panel sweep less per step, same formula as lanczos.h.
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -206,12 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int g = lane / LPR, cl = lane % LPR;
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
-  const int first = (j == 0);
+  const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
   const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
   F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
   const int colbase = panel * PW + cl * V;
+  VF accx = (VF)(F)0;
   VF sc, cp, cb = (VF)(F)0;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
             if (i < rc) w -= *(const VF *)(gl + i * PW + cl * V) * u[i];
           stream_store<SP>((VF *)(wn + ro), w);
           acc1 += w * w;
+          accx += w * xc;
         }
       }
     }
@@ -302,6 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
         block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
   } else {
     block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+    if (PASS == PASS_UPDATE && xt)
+      block_reduce_columns<F, LPR>(accx, red, part + (nblk + blockIdx.x) * bpad + panel * PW);
   }
 }
 
@@ -799,6 +806,7 @@ struct StepState {
   double *coefA;   // [2][bpad]     sc, cp for the next sweep A
   double *coefB;   // [bpad]        cB for sweep B
   double *gamma;   // [rmax][bpad]
+  double *cross;   // [bpad]        W_{j+1} . W_j from the fused update pass (k_csr_pass xt)
   int *active;     // [bpad]
   int *steps;      // [bpad]
   int bpad, nprobes, deg;
@@ -853,12 +861,14 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_init(StepState st, const do
 
 // After sweep A of step j: alpha_j, and the sweep-B coefficient cB = alpha_j / nu_j.
 __global__ __launch_bounds__(kFinThreads) void k_fin_alpha(StepState st, const double *__restrict__ partA,
-                                                   int nblk, int j) {
+                                                   int nblk, int j, int xt) {
   __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const double a = sum_partials(partA, nblk, st.bpad, col, red4);
+  double a = sum_partials(partA, nblk, st.bpad, col, red4);
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
     const int act = st.active[col];
+    // the alpha pass left out -beta q_c.q_p: q_c = sc W_c, beta q_p = cp W_p, W_c.W_p = cross
+    if (xt) a -= st.coefA[col] * st.coefA[st.bpad + col] * st.cross[col];
     if (act) st.alpha[(int64_t)j * st.bpad + col] = a;
     st.coefB[col] = act ? a / st.nu[(int64_t)j * st.bpad + col] : 0.0;
   }
@@ -866,10 +876,14 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_alpha(StepState st, const d
 
 // After the last sweep of step j: beta_{j+1} = ||w||, stop rule (lanczos.h:139-142), next sc/cp.
 __global__ __launch_bounds__(kFinThreads) void k_fin_beta(StepState st, const double *__restrict__ partN,
-                                                  int nblk, int j, double residual_tol) {
+                                                  int nblk, int j, double residual_tol, int xt) {
   __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const double s = sum_partials(partN, nblk, st.bpad, col, red4);
+  if (xt) {
+    const double x = sum_partials(partN + (int64_t)nblk * st.bpad, nblk, st.bpad, col, red4);
+    if ((threadIdx.x >> 6) == 0 && col < st.bpad) st.cross[col] = x;
+  }
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
     double sc = 0.0, cp = 0.0;
     if (st.active[col]) {
