@@ -12,7 +12,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "_libslq.so"
+## PRIMATE_AMD_LIBSLQ: load another build of the same library (kernel experiments, scripts/); no other effect
+LIB_PATH = Path(os.environ["PRIMATE_AMD_LIBSLQ"]) if os.environ.get("PRIMATE_AMD_LIBSLQ") else _HERE / "_libslq.so"
 
 SLQ_OK, SLQ_EINVAL, SLQ_ENOMEM, SLQ_EHIP, SLQ_ENODEV, SLQ_ECALLBACK, SLQ_ENOTCONV = 0, -1, -2, -3, -4, -5, -6
 SLQ_F32, SLQ_F64 = 0, 1

@@ -1,0 +1,62 @@
+"""Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/collect_profiles.sh) into
+profiles/pmc_summary.json: per kernel class, the average HBM bytes per launch, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE counts half of the wide reads; both counters are in KiB). The x2 is checked on a kernel whose
+traffic is known exactly: k_gen_probes writes one panel sweep, the ||v||^2 sweep k_axpy_norm<.,.,1> reads one."""
+
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+out_dir = sys.argv[1]
+
+
+def classify(name: str, orth: int):
+	m = re.search(r"k_csr_pass<(\w+), (\d+), (\d), ", name)
+	if m:
+		return {"0": "spmm_3term", "1": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm"}[m.group(3)]
+	for k, c in (("k_spmm_3term", "spmm_3term"), ("k_reorth_dot", "reorth_dot"), ("k_reorth_update", "reorth_update")):
+		if k in name:
+			return c
+	if "k_axpy_norm" in name:
+		return "probe_norm" if re.search(r"k_axpy_norm<\w+, \d+, 1>", name) else "axpy_norm"
+	if "k_gen_probes" in name:
+		return "gen_probes"
+	return None
+
+
+summary = {}
+for orth in (3, 0):
+	per = defaultdict(lambda: defaultdict(list))
+	names = {}
+	for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+		for f in glob.glob(f"{out_dir}/pmc_{counter}_orth{orth}/**/*counter_collection.csv", recursive=True):
+			with open(f) as fh:
+				for row in csv.DictReader(fh):
+					if row.get("Counter_Name") != counter:
+						continue
+					cls = classify(row["Kernel_Name"], orth)
+					if cls:
+						per[cls][counter].append(float(row["Counter_Value"]))
+						names[cls] = row["Kernel_Name"].split("(")[0]
+	if not per:
+		continue
+	entry = {}
+	for cls, d in per.items():
+		fs, ws = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
+		if not fs or not ws:
+			continue
+		fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
+		entry[cls] = {
+			"kernel": names[cls],
+			"launches_sampled": min(len(fs), len(ws)),
+			"FETCH_SIZE_KiB_avg": fa,
+			"WRITE_SIZE_KiB_avg": wa,
+			"hbm_bytes_per_launch": int((2 * fa + wa) * 1024),
+			"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; check rows: gen_probes writes and probe_norm reads exactly one panel sweep (s*n*b bytes)",
+		}
+	summary[f"lap2d_1000/P256/k30/orth{orth}"] = entry
+json.dump(summary, sys.stdout, indent=1)
