@@ -272,10 +272,11 @@ def main():
 
 		rng = np.random.default_rng(1234)
 		mk = lambda c: np.asfortranarray(np.floor(rng.random((n, c)) * 2) * 2 - 1)  # noqa: E731
+		oracle.quad_batch(A, mk(1), deg, orth, fun=args.fun, fresh_q=False, nthreads=1)  # builds the CSC copy, warms up
 		t = time.perf_counter()
-		oracle.quad_batch(A, mk(1), deg, orth, fun=args.fun, fresh_q=False, nthreads=1)
-		one = time.perf_counter() - t
-		cnt = int(max(2, min(32, args.cpu_seconds / max(one, 1e-3))))
+		oracle.quad_batch(A, mk(2), deg, orth, fun=args.fun, fresh_q=False, nthreads=1)
+		one = (time.perf_counter() - t) / 2
+		cnt = int(max(2, min(128, args.cpu_seconds / max(one, 1e-3))))
 		X = mk(cnt)
 		t = time.perf_counter()
 		qc = oracle.quad_batch(A, X, deg, orth, fun=args.fun, fresh_q=False, nthreads=1)

@@ -16,16 +16,16 @@ python3 $B --orth 30 --no-cpu-baseline --steps 4 > $OUT/bench_orth30_line.json
 python3 $B --workload lap3d_100 --no-cpu-baseline > $OUT/bench_lap3d_100_line.json
 for o in 3 0 30; do
   echo "== kernel stats orth $o"
-  rocprofv3 --kernel-trace --stats -d $OUT/stats_orth$o -o run -- python3 $B --orth $o --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_orth${o}_line_under_rocprof.json
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_orth$o -o run -- python3 $B --orth $o --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_orth${o}_line_under_rocprof.json
 done
 for o in 3 0; do
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $c orth $o"
-    rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${c}_orth$o -o run -- python3 $B --orth $o --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
+    rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_orth$o -o run -- python3 $B --orth $o --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
   done
 done
 python3 $ROOT/scripts/summarise_pmc.py $OUT > $OUT/pmc_summary.json
-find $OUT -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $(dirname $f))); cp $f $OUT/${d}_kernel_stats.csv 2>/dev/null || true; done
+find $OUT -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $f)); cp $f $OUT/${d}_kernel_stats.csv 2>/dev/null || true; done
 # the raw traces are large: keep summaries only
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
 du -sh $OUT
