@@ -183,6 +183,10 @@ int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, d
 int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,
                      double alpha, double beta);
 int slq_plan_fun_action_dmat(slq_plan *plan, int fun_id, const double *fun_params, slq_dmat *OUT, int o0);
+/* The plan's current probes (set or device-generated, not yet consumed by a run), as the estimators use
+ * them (sphere draws scaled to norm sqrt(n), src/primate/random.py:36-41), into OUT's columns
+ * [o0, o0 + nprobes): lets xtrace keep its sample matrix W on the device without a host draw. */
+int slq_plan_get_probes_dmat(slq_plan *plan, slq_dmat *OUT, int o0);
 
 /* Device bandwidth probe with the access shape of the sweeps (16 B/lane, one contiguous window):
  * mode 0 = two read streams, 1 = in-place triad (2 reads + 1 write), 2 = copy. Reports GB/s. Used by

@@ -1672,6 +1672,24 @@ extern "C" int slq_plan_fun_action_dmat(slq_plan *p, int fun_id, const double *f
   return SLQ_OK;
 }
 
+extern "C" int slq_plan_get_probes_dmat(slq_plan *p, slq_dmat *OUT, int o0) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  if (!p->probes_ready) return fail(SLQ_EINVAL, "no probes set, or they were consumed by a run");
+  SLQ_TRY(dmat_range(OUT, o0, p->nprobes, "slq_plan_get_probes_dmat"));
+  if (p->dtype != SLQ_F64 || OUT->n != p->n || OUT->ctx != p->ctx) return fail(SLQ_EINVAL, "plan and matrix do not match (fp64, same n, same context)");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  // the probes as the estimators see them: sphere probes are stored as the normal draw g and used as
+  // sqrt(n) g / ||g|| (k_fin_init), so the copy carries that scale (coefB is free until the run starts)
+  k_probe_scale<<<dim3((p->bpad + 255) / 256), dim3(256), 0, st>>>(p->st, p->st.coefB);
+  dim3 g((p->n + 63) / 64, (p->nprobes + 63) / 64);
+  hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, 0), 0, p->nprobes,
+                     OUT->d + (size_t)o0 * p->n, p->PW, (const double *)p->st.coefB, p->op->perm_d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return SLQ_OK;
+}
+
 extern "C" int slq_measure_stream(slq_context *ctx, int mode, size_t bytes_per_stream, int reps, double *gbps) {
   if (!ctx || !gbps || mode < 0 || mode > 2 || reps < 1 || bytes_per_stream < (1u << 20))
     return fail(SLQ_EINVAL, "bad arguments");

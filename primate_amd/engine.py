@@ -205,6 +205,10 @@ class LanczosPlan:
 		check(_capi.lib().slq_plan_get_probes(self._h, ptr(X), X.shape[0]))
 		return X
 
+	def get_probes_into(self, out: "DeviceMatrix", o0: int):
+		"""The current probes (as used: sphere draws have norm sqrt(n)) into columns [o0, o0 + nprobes) of `out`."""
+		check(_capi.lib().slq_plan_get_probes_dmat(self._h, out._h, int(o0)))
+
 	def run(self, rtol: float = 1e-8):
 		rc = _capi.lib().slq_plan_run(self._h, float(rtol))
 		if rc == _capi.SLQ_ECALLBACK and getattr(self.op, "error", None) is not None:

@@ -181,7 +181,7 @@ def _qr_append_block(Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, Y: np.ndar
 	return np.c_[Q, Qn], R_new, Ri_new
 
 
-def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, callback: Callable, result: EstimatorResult):
+def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, callback: Callable, result: EstimatorResult, device_rng=None):
 	"""xtrace for a device `MatrixFunction` with everything n-sized resident on the GPU: the sketches
 	W, Q, Z are column-major device matrices; f(A)·(new probes) and f(A)·(new Q columns) are lock-step
 	Lanczos batches whose outputs never leave HBM; the block Gram-Schmidt + CholeskyQR2 and the
@@ -211,8 +211,15 @@ def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, cal
 	try:
 		while m < P:
 			ns = min(int(batch), P - m)
-			Wd.set(m, draw(size=(n, ns)))
-			apply_fun(Wd, m, ns, Yd, 0)
+			if device_rng is None:
+				Wd.set(m, draw(size=(n, ns)))
+				apply_fun(Wd, m, ns, Yd, 0)
+			else:
+				plan = A._plan(ns, True)
+				plan.generate_probes(device_rng[0], seed=device_rng[1], probe_offset=m)
+				plan.get_probes_into(Wd, m)
+				plan.run(A._rtol)
+				plan.fun_action_into(Yd, 0, name, **kw)
 			## block Gram-Schmidt against the existing Q, twice
 			Cm = np.zeros((m, ns))
 			if m > 0:
@@ -284,6 +291,8 @@ def xtrace(
 	result = EstimatorResult()
 	rng = np.random.default_rng(seed)
 	draw = isotropic(pdf=pdf, seed=rng) if isinstance(pdf, str) else pdf
+	## extra keyword: draw the probes on the device too (device path only; a different, equally valid stream)
+	device_rng = (pdf, int(seed) if isinstance(seed, (int, np.integer)) else int(rng.integers(0, 2**62))) if (kwargs.pop("device_rng", False) and isinstance(pdf, str)) else None
 	## Parity note: the reference rebinds `pdf` to the sampler closure before handing it to _xtrace
 	## (trace.py:295 then :305), so its `pdf == "sphere"` test (trace.py:207) is never true and the
 	## sphere rescaling is never applied. Same here: results match the reference for every pdf.
@@ -294,7 +303,7 @@ def xtrace(
 		isinstance(A, MatrixFunction) and A._builtin is not None and A.dtype == np.float64 and not A._stale_ring
 		and kwargs.pop("device", True)
 	):  # fmt: skip
-		_xtrace_device(A, batch, draw, stop.count, record, callback, result)
+		_xtrace_device(A, batch, draw, stop.count, record, callback, result, device_rng)
 		result.criterion = stop
 		return (result.estimate, result) if full else result.estimate
 	while not stop(estimator):

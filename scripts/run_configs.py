@@ -103,7 +103,7 @@ if "c3x" in which:
     W = ((W + W.T) > 0).astype(np.float64).tocsr(); W.sort_indices()
     M = MatrixFunction(W, fun="exp", deg=k, orth=3)
     t0 = time.time(); marks = []
-    est, info = xtrace(M, batch=128, seed=1234, count=P, full=True, callback=lambda r: marks.append((r.nit, float(r.estimate), time.time() - t0)))
+    est, info = xtrace(M, batch=128, seed=1234, count=P, full=True, device_rng=bool(int(os.environ.get("C3_DEVICE_RNG", "1"))), callback=lambda r: marks.append((r.nit, float(r.estimate), time.time() - t0)))
     dt = time.time() - t0
     t0 = time.time(); h = hutch(M, converge="count", count=P, seed=1234); dth = time.time() - t0
     out["c3x"] = dict(n=n, nnz=int(W.nnz), k=k, probes=P, xtrace_seconds=dt, xtrace_estimate=float(est), progress=marks, hutch_seconds=dth, hutch_estimate=float(h))

@@ -274,3 +274,34 @@ def test_sharded_drivers_single_rank(golden):
 	ew, ev = np.linalg.eigh(L.toarray())
 	exact = np.einsum("ij,j,ij->i", ev, np.exp(-0.1 * ew), ev)
 	assert c == 40 and np.all(denom == 40) and np.linalg.norm(est - exact) / np.linalg.norm(exact) < 0.15
+
+
+def test_xtrace_device_rng_and_probe_export():
+	"""Device-drawn xtrace probes: the exported sample matrix equals what the plan generator produces
+	(sphere draws scaled to norm sqrt(n)), and the estimate agrees with the host-drawn one statistically."""
+	from primate_amd.engine import DeviceMatrix, DeviceOperator, LanczosPlan
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import xtrace
+
+	L = laplacian_2d(24)
+	n = L.shape[0]
+	op = DeviceOperator(L)
+	plan = LanczosPlan(op, 12, 20, 3, keep_basis=True)
+	W = DeviceMatrix(n, 24, ctx=op.ctx)
+	for pdf in ("rademacher", "normal", "sphere"):
+		plan.generate_probes(pdf, seed=9, probe_offset=4)
+		X = plan.get_probes()
+		plan.get_probes_into(W, 12)
+		G = W.get(12, 12)
+		if pdf == "sphere":
+			np.testing.assert_allclose(np.linalg.norm(G, axis=0), np.sqrt(n), rtol=1e-13)
+			np.testing.assert_allclose(G, X * (np.sqrt(n) / np.linalg.norm(X, axis=0)), rtol=1e-13)
+		else:
+			np.testing.assert_array_equal(G, X)
+	M = MatrixFunction(L, fun="exp", deg=20, orth=3, t=-0.5)
+	exact = np.sum(np.exp(-0.5 * np.linalg.eigvalsh(L.toarray())))
+	a = xtrace(M, batch=16, seed=3, count=64, device_rng=True)
+	b = xtrace(M, batch=16, seed=3, count=64)
+	assert abs(a - exact) / exact < 2e-2 and abs(b - exact) / exact < 2e-2
+	## same seed, same stream: reproducible
+	assert a == xtrace(M, batch=16, seed=3, count=64, device_rng=True)
