@@ -136,6 +136,21 @@ class MatrixFunction(LinearOperator):
 		self._nodes[:], self._weights[:] = nodes[-1], weights[-1]
 		return y
 
+	def quad_generated(self, nprobes: int, pdf: str = "rademacher", seed: int = 0, probe_offset: int = 0) -> np.ndarray:
+		"""v_i^T f(A) v_i for `nprobes` probes DRAWN ON THE DEVICE (Philox stream of probe ids probe_offset..;
+		slq_plan_generate_probes): the throughput form of `quad`, with no n x nprobes host array at all."""
+		assert not self._stale_ring, "device-drawn probes start from a clean ring"
+		plan = self._plan(int(nprobes), False)
+		plan.generate_probes(pdf, seed=int(seed), probe_offset=int(probe_offset))
+		plan.run(self._rtol)
+		if self._builtin is not None:
+			name, kw = self._builtin
+			y, nodes, weights = plan.quadrature(name, return_rule=True, **kw)
+		else:
+			y, nodes, weights = plan.quadrature(self._fun, return_rule=True)
+		self._nodes[:], self._weights[:] = nodes[-1], weights[-1]
+		return y
+
 	def _quad_reference_ring(self, x: np.ndarray) -> np.ndarray:
 		"""The reference loop verbatim in structure (operators.py:145-150): per column, the native
 		single-vector Lanczos on the persistent alpha/beta/Q, then the Gauss rule, then the sum."""

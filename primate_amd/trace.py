@@ -52,7 +52,21 @@ def hutch(
 	f_dtype = is_valid_operator(A)
 	N: int = A.shape[0]
 	rng = np.random.default_rng(seed)
-	pdf = isotropic(pdf=pdf, seed=rng) if isinstance(pdf, str) else pdf
+	## pdf="device:<name>" (extension): probes drawn on the GPU, ids 0, 1, 2, ... of the Philox stream `seed`
+	dev_pdf = pdf[len("device:"):] if isinstance(pdf, str) and pdf.startswith("device:") else None
+	if dev_pdf is not None:
+		assert hasattr(A, "quad_generated"), "device-drawn probes need a MatrixFunction (primate_amd.operators)"
+		dev_seed = int(seed) if isinstance(seed, (int, np.integer)) else int(rng.integers(0, 2**62))
+		drawn = [0]
+
+		def quad_next(m: int) -> np.ndarray:
+			y = A.quad_generated(m, dev_pdf, dev_seed, drawn[0])
+			drawn[0] += m
+			return y
+
+		pdf = None
+	else:
+		pdf = isotropic(pdf=pdf, seed=rng) if isinstance(pdf, str) else pdf
 	estimator = MeanEstimator(covariance=True, record=kwargs.pop("record", False))
 	if isinstance(converge, str) and converge == "default":
 		converge = CountCriterion(count=200) | ConfidenceCriterion(confidence=0.95, atol=1.0, rtol=0.0)
@@ -66,8 +80,7 @@ def hutch(
 		result = EstimatorResult(estimator, converge)
 		callback = (lambda x: x) if callback is None else callback
 		while not converge(estimator):
-			v = pdf(size=(N, batch)).astype(f_dtype)
-			estimator.update(quad_form(v))
+			estimator.update(quad_next(batch) if dev_pdf is not None else quad_form(pdf(size=(N, batch)).astype(f_dtype)))
 			callback(result)
 		result.message = converge.message(estimator)
 		result.estimate, result.nit = estimator.estimate, len(estimator)
@@ -78,7 +91,7 @@ def hutch(
 		m = batch
 		if isinstance(converge, CountCriterion):
 			m = max(1, min(batch if not hasattr(A, "quad") else max(batch, 256), converge.count - len(estimator)))
-		ys = np.atleast_1d(quad_form(pdf(size=(N, m)).astype(f_dtype)))
+		ys = np.atleast_1d(quad_next(m) if dev_pdf is not None else quad_form(pdf(size=(N, m)).astype(f_dtype)))
 		for y in ys:
 			estimator.update(y)
 			if converge(estimator):

@@ -106,7 +106,8 @@ if "c3x" in which:
     est, info = xtrace(M, batch=128, seed=1234, count=P, full=True, device_rng=bool(int(os.environ.get("C3_DEVICE_RNG", "1"))), callback=lambda r: marks.append((r.nit, float(r.estimate), time.time() - t0)))
     dt = time.time() - t0
     t0 = time.time(); h = hutch(M, converge="count", count=P, seed=1234); dth = time.time() - t0
-    out["c3x"] = dict(n=n, nnz=int(W.nnz), k=k, probes=P, xtrace_seconds=dt, xtrace_estimate=float(est), progress=marks, hutch_seconds=dth, hutch_estimate=float(h))
+    t0 = time.time(); hd = hutch(M, pdf="device:rademacher", converge="count", count=P, seed=1234); dthd = time.time() - t0
+    out["c3x"] = dict(n=n, nnz=int(W.nnz), k=k, probes=P, xtrace_seconds=dt, xtrace_estimate=float(est), progress=marks, hutch_seconds=dth, hutch_estimate=float(h), hutch_device_rng_seconds=dthd, hutch_device_rng_estimate=float(hd))
     print(json.dumps({"c3x": out["c3x"]}), flush=True)
 
 (ROOT / "gpurun_out").mkdir(exist_ok=True)

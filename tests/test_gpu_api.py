@@ -305,3 +305,25 @@ def test_xtrace_device_rng_and_probe_export():
 	assert abs(a - exact) / exact < 2e-2 and abs(b - exact) / exact < 2e-2
 	## same seed, same stream: reproducible
 	assert a == xtrace(M, batch=16, seed=3, count=64, device_rng=True)
+
+
+def test_hutch_device_drawn_probes():
+	"""hutch(pdf="device:rademacher"): same values as evaluating the generated probes explicitly, and the
+	stream does not depend on the batch size."""
+	from primate_amd.engine import DeviceOperator, LanczosPlan
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch
+
+	L = laplacian_2d(30)
+	M = MatrixFunction(L, fun="log", deg=20, orth=3)
+	a = hutch(M, pdf="device:rademacher", converge="count", count=96, seed=11, batch=32)
+	b, info = hutch(M, pdf="device:rademacher", converge="count", count=96, seed=11, batch=48, full=True)
+	op = DeviceOperator(L)
+	plan = LanczosPlan(op, 96, 20, 3)
+	plan.generate_probes("rademacher", seed=11)
+	X = plan.get_probes()
+	q = M.quad(X)
+	assert a == pytest.approx(q.mean(), rel=1e-12) and b == pytest.approx(q.mean(), rel=1e-12)
+	assert info.nit == 96
+	exact = np.sum(np.log(np.linalg.eigvalsh(L.toarray())))
+	assert abs(a - exact) / abs(exact) < 0.05
