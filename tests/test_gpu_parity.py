@@ -455,6 +455,43 @@ def test_opt_in_row_reordering_is_transparent(oracle, eng, monkeypatch):
 	np.testing.assert_allclose(denom, np.sum(X * X, axis=1), rtol=1e-12)
 
 
+def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, monkeypatch):
+	"""The alpha pass gathers only the upper triangle when the stored CSR is exactly symmetric, and keeps
+	full rows otherwise: (a) symmetric operator, all three variants (upper triangle + cross term, each
+	switched off) agree with the oracle; (b) an operator that is NOT symmetric goes through the same
+	arithmetic as the oracle's recurrence (lanczos.h never checks symmetry), so alpha/beta still match."""
+	A = random_spd_graph(1501, 5.0, seed=3)
+	rng = np.random.default_rng(8)
+	X = np.asfortranarray(rng.standard_normal((1501, 20)))
+	for orth in (0, 3):
+		ref = oracle.quad_batch(A, X, 18, orth, fun="log", fresh_q=True, prefer="csr")
+		for env in ({}, {"SLQ_SYM_ALPHA": "0"}, {"SLQ_CROSS": "0"}, {"SLQ_SYM_ALPHA": "0", "SLQ_CROSS": "0"}):
+			for k, v in env.items():
+				monkeypatch.setenv(k, v)
+			op = eng.DeviceOperator(A)
+			np.testing.assert_allclose(eng.quad_batch(op, X, 18, orth, fun="log"), ref, rtol=1e-10, err_msg=f"{env} orth={orth}")
+			op.close()
+			for k in env:
+				monkeypatch.delenv(k)
+	## (b) perturb one off-diagonal entry: no longer symmetric
+	B = A.copy().tolil()
+	i, j = np.transpose(sp.triu(A, 1).nonzero())[7]
+	B[i, j] = B[i, j] * 1.5
+	B = B.tocsr()
+	B.sort_indices()
+	op = eng.DeviceOperator(B)
+	for orth in (0, 3):
+		plan = eng.LanczosPlan(op, 20, 12, orth)
+		plan.set_probes(X)
+		plan.run()
+		a, b, _ = plan.tridiag()
+		for c in (0, 7, 19):
+			ar, br, Qr = np.zeros(13), np.zeros(13), np.zeros((1501, max(orth, 2)), order="F")
+			oracle.lanczos(B, X[:, c].copy(), 12, 1e-8, orth, ar, br, Qr)
+			np.testing.assert_allclose(a[c][:12], ar[:12], rtol=1e-9, atol=1e-9)
+			np.testing.assert_allclose(b[c][1:12], br[1:12], rtol=1e-9, atol=1e-9)
+
+
 def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 	"""SLQ_TILES=1: the experimental LDS-staged fused passes (k_csr_pass_tiled) give the generic
 	passes' results to rounding, for both tile heights and with/without reorthogonalisation."""
