@@ -179,6 +179,7 @@ int slq_dmat_destroy(slq_dmat *m);
 int slq_dmat_set(slq_dmat *m, int c0, int nc, const double *host, int64_t ld);
 int slq_dmat_get(slq_dmat *m, int c0, int nc, double *host, int64_t ld);
 int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr);
+int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int nc); /* dst[:, d0:d0+nc] = src[:, s0:s0+nc], on the device */
 int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host);
 int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,
                      double alpha, double beta);

@@ -79,6 +79,7 @@ _SIGNATURES = {
 	"slq_dmat_gemm_nn": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_double, C.c_double]),
 	"slq_plan_fun_action_dmat": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
 	"slq_plan_get_probes_dmat": (C.c_int, [_P, _P, C.c_int]),
+	"slq_dmat_copy": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
 	"slq_measure_stream": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 	"slq_plan_set_probes_device": (C.c_int, [_P, _P, C.c_int64]),
 	"slq_fttr_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -1606,6 +1606,17 @@ extern "C" int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr) {
   return SLQ_OK;
 }
 
+extern "C" int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int nc) {
+  SLQ_TRY(dmat_range(dst, d0, nc, "slq_dmat_copy(dst)"));
+  SLQ_TRY(dmat_range(src, s0, nc, "slq_dmat_copy(src)"));
+  if (dst->n != src->n || dst->ctx != src->ctx) return fail(SLQ_EINVAL, "mismatched operands");
+  HIP_TRY(hipSetDevice(dst->ctx->device));
+  HIP_TRY(hipMemcpyAsync(dst->d + (size_t)d0 * dst->n, src->d + (size_t)s0 * src->n, (size_t)nc * dst->n * 8,
+                         hipMemcpyDeviceToDevice, dst->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(dst->ctx->stream));
+  return SLQ_OK;
+}
+
 extern "C" int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host) {
   SLQ_TRY(dmat_range(A, a0, ma, "slq_dmat_gemm_tn(A)"));
   SLQ_TRY(dmat_range(B, b0, mb, "slq_dmat_gemm_tn(B)"));

@@ -134,3 +134,43 @@ def sharded_diag_device(op, nprobes: int, deg: int, orth: int = 3, fun="identity
 	with np.errstate(divide="ignore", invalid="ignore"):
 		est = numer / denom
 	return est, numer, denom, cnt
+
+
+def allgather_columns(src, ncols: int, dst, group=None):
+	"""dst[:, r*ncols:(r+1)*ncols] = rank r's src[:, :ncols] for every rank r: the exchange step of a
+	column-sharded f(A)-product (xtrace). Backend "nccl" (RCCL over xGMI) gathers the device
+	buffers in place through zero-copy torch views; any other backend (gloo in the tests) stages through
+	the host."""
+	import torch
+	import torch.distributed as dist
+
+	world = dist.get_world_size(group)
+	if dist.get_backend(group) == "nccl":
+		dev = f"cuda:{src.ctx.device if src.ctx.device >= 0 else torch.cuda.current_device()}"
+		tin = torch.as_tensor(src.cuda_array(0, ncols), device=dev)
+		tout = torch.as_tensor(dst.cuda_array(0, ncols * world), device=dev)
+		src.ctx.synchronize()  # libslq writes on its own stream
+		dist.all_gather_into_tensor(tout, tin, group=group)
+		torch.cuda.synchronize(dev)
+		return
+	loc = torch.from_numpy(np.ascontiguousarray(src.get(0, ncols).T))  # (ncols, n): rows = columns
+	parts = [torch.empty_like(loc) for _ in range(world)]
+	dist.all_gather(parts, loc, group=group)
+	dst.set(0, np.concatenate([p.numpy().T for p in parts], axis=1))
+
+
+def sharded_xtrace(M, count: int, batch: int = 128, pdf: str = "sphere", seed: int = 0, group=None, full: bool = False, device_rng: bool = True):
+	"""XTrace of a device `MatrixFunction` with the f(A)-products of every block split by column over the
+	ranks of `group` (BASELINE.json configs[2]: "512 probes, 1 -> 8 GPUs probe-sharded"). Every rank must
+	call it with the same arguments; every rank returns the same estimate. Two all-gathers of n x batch
+	doubles per block (Y = f(A) W and Z = f(A) Q_new) are the only collectives; the sample matrix W is
+	replicated without communication because all ranks draw it from the same (seed, probe id) stream."""
+	import torch.distributed as dist
+
+	from .trace import xtrace
+
+	if not dist.is_initialized() or dist.get_world_size(group) == 1:
+		return xtrace(M, batch=batch, pdf=pdf, seed=seed, count=count, full=full, device_rng=device_rng)
+	rank, world = dist.get_rank(group), dist.get_world_size(group)
+	shard = (rank, world, lambda src, ncols, dst: allgather_columns(src, ncols, dst, group))
+	return xtrace(M, batch=batch, pdf=pdf, seed=seed, count=count, full=full, device_rng=device_rng, _shard=shard)

@@ -376,6 +376,14 @@ class DiagAccumulator:
 			pass
 
 
+class _CudaArrayView:
+	"""Flat fp64 device array described by the CUDA array interface (v2); keeps its owner alive."""
+
+	def __init__(self, dptr: int, count: int, owner):
+		self._owner = owner
+		self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(dptr), False), "version": 2}
+
+
 class DeviceMatrix:
 	"""Column-major n x cols fp64 matrix on the GPU with the two tall-skinny products of the
 	exchangeable estimators (slq_dmat_*: fp64 MFMA)."""
@@ -401,6 +409,16 @@ class DeviceMatrix:
 		p = C.c_void_p()
 		check(_capi.lib().slq_dmat_ptr(self._h, int(c0), C.byref(p)))
 		return p.value
+
+	def copy_from(self, d0: int, src: "DeviceMatrix", s0: int, nc: int):
+		"""self[:, d0:d0+nc] = src[:, s0:s0+nc] (device to device)."""
+		check(_capi.lib().slq_dmat_copy(self._h, int(d0), src._h, int(s0), int(nc)))
+
+	def cuda_array(self, c0: int, nc: int):
+		"""Columns [c0, c0+nc) as a flat object with `__cuda_array_interface__` (zero-copy view for
+		torch.as_tensor(..., device="cuda"): the RCCL collectives of primate_amd.distributed)."""
+		assert 0 <= c0 and nc > 0 and c0 + nc <= self.cols
+		return _CudaArrayView(self.col_ptr(c0), self.n * int(nc), self)
 
 	def tn(self, a0: int, ma: int, B: "DeviceMatrix", b0: int, mb: int) -> np.ndarray:
 		"""self[:, a0:a0+ma].T @ B[:, b0:b0+mb]  (ma x mb, on the host)."""

@@ -194,7 +194,7 @@ def _qr_append_block(Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, Y: np.ndar
 	return np.c_[Q, Qn], R_new, Ri_new
 
 
-def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, callback: Callable, result: EstimatorResult, device_rng=None):
+def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, callback: Callable, result: EstimatorResult, device_rng=None, shard=None):
 	"""xtrace for a device `MatrixFunction` with everything n-sized resident on the GPU: the sketches
 	W, Q, Z are column-major device matrices; f(A)·(new probes) and f(A)·(new Q columns) are lock-step
 	Lanczos batches whose outputs never leave HBM; the block Gram-Schmidt + CholeskyQR2 and the
@@ -215,17 +215,42 @@ def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, cal
 	estimator = MeanEstimator(record=record)
 	m = 0
 
-	def apply_fun(src: "engine.DeviceMatrix", c0: int, ns: int, dst: "engine.DeviceMatrix", o0: int):
+	def apply_fun_local(src: "engine.DeviceMatrix", c0: int, ns: int, dst: "engine.DeviceMatrix", o0: int):
 		plan = A._plan(ns, True)
 		plan.set_probes_device(src.col_ptr(c0))
 		plan.run(A._rtol)
 		plan.fun_action_into(dst, o0, name, **kw)
 
+	Sd = Gd = None
+	if shard is not None:
+		rank, world, allgather = shard
+		cmax = -(-int(batch) // world)  # columns per rank and block, padded to equal shards for the all-gather
+		Sd, Gd = engine.DeviceMatrix(n, cmax, ctx=ctx), engine.DeviceMatrix(n, cmax * world, ctx=ctx)
+
+	def apply_fun(src: "engine.DeviceMatrix", c0: int, ns: int, dst: "engine.DeviceMatrix", o0: int):
+		if shard is None:
+			return apply_fun_local(src, c0, ns, dst, o0)
+		base, rem = divmod(ns, world)
+		lo = rank * base + min(rank, rem)
+		nloc = base + (1 if rank < rem else 0)
+		if nloc > 0:
+			apply_fun_local(src, c0 + lo, nloc, Sd, 0)
+		allgather(Sd, cmax, Gd)
+		for r in range(world):  # rank r's valid columns are the first base (+1) of its cmax-wide slab
+			rl, rn = r * base + min(r, rem), base + (1 if r < rem else 0)
+			if rn > 0:
+				dst.copy_from(o0 + rl, Gd, r * cmax, rn)
+
 	try:
 		while m < P:
 			ns = min(int(batch), P - m)
-			if device_rng is None:
-				Wd.set(m, draw(size=(n, ns)))
+			if device_rng is None or shard is not None:
+				if device_rng is None:
+					Wd.set(m, draw(size=(n, ns)))
+				else:
+					plan = A._plan(ns, True)
+					plan.generate_probes(device_rng[0], seed=device_rng[1], probe_offset=m)
+					plan.get_probes_into(Wd, m)
 				apply_fun(Wd, m, ns, Yd, 0)
 			else:
 				plan = A._plan(ns, True)
@@ -266,8 +291,9 @@ def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, cal
 			result.estimator, result.estimate, result.nit = estimator, estimator.estimate, m
 			callback(result)
 	finally:
-		for d in (Wd, Qd, Zd, Yd, Td):
-			d.close()
+		for d in (Wd, Qd, Zd, Yd, Td, Sd, Gd):
+			if d is not None:
+				d.close()
 	return result
 
 
@@ -316,7 +342,7 @@ def xtrace(
 		isinstance(A, MatrixFunction) and A._builtin is not None and A.dtype == np.float64 and not A._stale_ring
 		and kwargs.pop("device", True)
 	):  # fmt: skip
-		_xtrace_device(A, batch, draw, stop.count, record, callback, result, device_rng)
+		_xtrace_device(A, batch, draw, stop.count, record, callback, result, device_rng, kwargs.pop("_shard", None))
 		result.criterion = stop
 		return (result.estimate, result) if full else result.estimate
 	while not stop(estimator):

@@ -1,0 +1,48 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a column-sharded xtrace (all ranks share GPU 0 in
+the rehearsal; on a real node each rank has its own GPU and the backend is nccl = RCCL)."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+	import torch.distributed as dist
+
+	backend, out = sys.argv[1], sys.argv[2]
+	dist.init_process_group(backend)
+	rank, world = dist.get_rank(), dist.get_world_size()
+	if os.environ.get("DIST_TEST_SHARE_GPU0"):
+		os.environ["LOCAL_RANK"] = "0"  # rehearsal on a 1-GPU box: every rank on device 0
+	from conftest import laplacian_2d
+	from primate_amd.distributed import allgather_columns, sharded_xtrace
+	from primate_amd.engine import DeviceMatrix
+	from primate_amd.operators import MatrixFunction
+
+	L = laplacian_2d(40)
+	M = MatrixFunction(L, fun="exp", deg=20, orth=3, t=-0.5)
+	res = {}
+	## ragged on purpose: 50 probes in blocks of 20 (20, 20, 10) over `world` ranks
+	est, info = sharded_xtrace(M, count=50, batch=20, pdf="sphere", seed=7, full=True)
+	res["estimate"], res["nit"] = float(est), int(info.nit)
+	## the collective itself, on known data
+	n = L.shape[0]
+	S, G = DeviceMatrix(n, 3, ctx=M._op.ctx), DeviceMatrix(n, 3 * world, ctx=M._op.ctx)
+	S.set(0, np.arange(n * 3, dtype=np.float64).reshape(n, 3, order="F") + 1000.0 * rank)
+	allgather_columns(S, 3, G)
+	got = G.get()
+	ok = all(np.array_equal(got[:, 3 * r : 3 * r + 3], np.arange(n * 3, dtype=np.float64).reshape(n, 3, order="F") + 1000.0 * r) for r in range(world))
+	res["gather_ok"] = bool(ok)
+	json.dump(res, open(f"{out}.rank{rank}.json", "w"))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()
