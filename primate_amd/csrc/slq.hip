@@ -763,9 +763,11 @@ static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nbl
   int per_xcd = std::min(std::max(8, num_cus * per_cu_a / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   per_xcd = std::max(per_xcd, 1);
   *nblkA = 8 * per_xcd;
-  // fused dots/update passes hold ~100 VGPRs (2 workgroups resident per CU): a grid of exactly one
-  // or two resident waves of workgroups avoids a ragged tail (4/CU measured best; 5-7 lose 10-20 %)
-  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 4));
+  // fused dots/update passes (62-96 VGPRs depending on the ring-column count: 2 or 3 workgroups fit a CU):
+  // one round of 2 workgroups per CU. More rows in flight evict each other's gather halo (dots pass 36.3 ms
+  // per 30 launches at 2/CU, 37.6 at 4, 41.3 at 3, 43.6 at 6), and a grid that is not a multiple of what is
+  // resident leaves a ragged second round (update pass at r = 0: 37.3 at 2/CU, 42.5 at 4).
+  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 2));
   int per_xcd_u = std::min(std::max(8, num_cus * per_cu_u / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   *nblkU = 8 * std::max(per_xcd_u, 1);
   int s = std::min(std::max(1, num_cus * per_cu_s / NP), (n + rows_per_block - 1) / rows_per_block);
@@ -911,14 +913,10 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 // raise their limit once, outside any stream capture.
 template <typename F, int L> static hipError_t raise_lds_limits() {
   hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)  // SLQ_ALPHA_LDS_PAD experiments
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 1, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0, kFusedMaxR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kFusedMaxR>,
                              (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kFusedMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kFusedMaxR>,
                              (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kFusedMaxR>};
@@ -1156,6 +1154,12 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
       const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0;
       const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
+#define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
+  DISPATCH(p->dtype, p->LPR,                                                                         \
+           (k_csr_pass<F, L, PASS, LP, RCT><<<(PASS == PASS_ALPHA ? gAf : gU), dim3(kBlock), LDS, st>>>( \
+               p->n, half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,             \
+               (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S, j,        \
+               p->st.coefA, p->st.coefB, p->st.gamma, p->part, bp, XT)))
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
   do {                                                                                               \
     if (tiled) {                                                                                     \
@@ -1169,11 +1173,13 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
     } else {                                                                                         \
       const bool half = PASS == PASS_ALPHA && op->rowptr_u != nullptr;                               \
-      DISPATCH(p->dtype, p->LPR,                                                                     \
-               (k_csr_pass<F, L, PASS, LP, SP, kFusedMaxR><<<(PASS == PASS_ALPHA ? gAf : gU), dim3(kBlock), LDS, st>>>( \
-                   p->n, half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,         \
-                   (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S,       \
-                   j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp, XT))); \
+      switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                       \
+        case 0: CSR_PASS_RC(PASS, LP, 0, LDS, XT); break;                                            \
+        case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                 \
+        case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                 \
+        case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                 \
+        default: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 4), LDS, XT); break;                \
+      }                                                                                              \
     }                                                                                                \
   } while (0)
       // alpha pass: residency is set by its grid (nblkF, slq_plan_create); SLQ_ALPHA_LDS_PAD can cap it
@@ -1191,10 +1197,11 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
                                     p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
       }
-      const size_t ldsU = lds0 + (size_t)r * p->PW * p->esz;
+      const size_t ldsU = lds0 + (tiled ? (size_t)r * p->PW * p->esz : 0);  // the tiled kernel stages gamma in LDS
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
                { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_u); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_u); });
 #undef CSR_PASS
+#undef CSR_PASS_RC
       nblk_last = tiled ? p->nblkT : p->nblkU;
       prev_xt = xt_u != 0;
     } else {

@@ -185,26 +185,29 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // Per step that is (2 + 2 max(r,2)) panel reads + 1 write (r > 0) or 4 reads + 1 write (r = 0)
 // against (2r + 4) reads + 3 writes / 4 reads + 2 writes for the store-and-revisit sweeps.
 // Ring columns t_0 = j (W_c) and t_1 = j-1 (W_p) are the rows the three-term part loads anyway.
-// DCH = compile-time capacity for ring columns per launch (registers); the host uses these passes
+// RC = compile-time number of ring columns (registers); the host uses these passes
 // for r <= kFusedMaxR and the store-and-revisit sweeps (k_reorth_dot / k_reorth_update) for deeper
 // reorthogonalisation, where the saved write no longer pays for re-gathering (measured).
 enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2 };
 
-template <typename F, int LPR, int PASS, int LP, int SP, int DCH>
+template <typename F, int LPR, int PASS, int NTP, int RC>
 __global__ __launch_bounds__(kBlock) void k_csr_pass(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
-    const F *__restrict__ vals, F *ring, int64_t slot_stride, int S, int j, int i0, int rc,
+    const F *__restrict__ vals, F *ring, int64_t slot_stride, int S, int j,
     const double *__restrict__ coefA, const double *__restrict__ coefB,
-    const double *__restrict__ gamma /* PASS_UPDATE: [rc][bpad] */, double *__restrict__ part,
+    const double *__restrict__ gamma /* PASS_UPDATE: [RC][bpad] */, double *__restrict__ part,
     int bpad, int xt) {
+  // RC = number of ring columns of this step (r_j, compile time: the loops below carry no runtime guards
+  // and every row's loads are issued back to back); column 0 is W_c, column 1 is W_p - the rows the
+  // three-term part holds anyway - columns i >= 2 are W_{j-i}. NTP: nontemporal policy for streamed rows.
   // xt (cross term): PASS_UPDATE also reduces X = sum_i w_{j+1}[i] w_j[i] into the second partial slab,
   // and the NEXT step's PASS_ALPHA then leaves W_p unread: alpha = q_c.(A q_c) - beta (q_c.q_p) with the
   // second dot taken from X (k_fin_alpha) - one panel sweep less per step, same formula as lanczos.h.
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  constexpr int NX = RC > 2 ? RC - 2 : 1;  // ring columns beyond W_c, W_p
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  double *red = (double *)lds_raw;                                 // kWaves*64*V doubles
-  F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);       // PASS_UPDATE: rc * PW
+  double *red = (double *)lds_raw;  // kWaves*64*V doubles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
   const int panel = blockIdx.y;
@@ -213,10 +216,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
   const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
   F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
-  const F *U0 = ring + poff;
+  const F *ux[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) ux[i] = ring + (int64_t)ring_slot(j - 2 - i, S) * slot_stride + poff;
   const int colbase = panel * PW + cl * V;
-  VF accx = (VF)(F)0;
   VF sc, cp, cb = (VF)(F)0;
+  VF gm[RC > 0 ? RC : 1];
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     sc[v] = (F)coefA[colbase + v];
@@ -224,9 +229,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
     if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
   }
   if (PASS == PASS_UPDATE) {
-    for (int t = threadIdx.x; t < rc * PW; t += kBlock)
-      gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RC; ++i)
+#pragma unroll
+      for (int v = 0; v < V; ++v) gm[i][v] = (F)gamma[(int64_t)i * bpad + colbase + v];
   }
   const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
   const int chunk = (n + 7) / 8;
@@ -234,11 +240,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int r_end = min(n, r_begin + chunk);
   const int stride = nbl * kWaves * RPW;
   VF acc1 = (VF)(F)0;  // alpha or norm partial
-  VF dacc[PASS == PASS_DOTS ? DCH : 1];
-  if (PASS == PASS_DOTS) {
+  VF accx = (VF)(F)0;  // cross term
+  VF dacc[RC > 0 ? RC : 1];
 #pragma unroll
-    for (int i = 0; i < DCH; ++i) dacc[i] = (VF)(F)0;
-  }
+  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = (VF)(F)0;
   for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
     int row = r0 + g;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
@@ -248,7 +253,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       // row-local operands first: their latency overlaps the dependent colind -> gather chain
       const VF xc = *(const VF *)(wc + ro);
       VF xp = (VF)(F)0;
-      if (!first) xp = stream_load<LP>((const VF *)(wp + ro));
+      if (!first) xp = stream_load<NTP>((const VF *)(wp + ro));
+      VF u[NX];
+      if (PASS != PASS_ALPHA && RC > 2) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) u[i] = stream_load<NTP>((const VF *)(ux[i] + ro));
+      }
       VF acc = (VF)(F)0;
       int p = p0;
       for (; p + 4 <= p1; p += 4) {
@@ -274,25 +284,17 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
         acc1 += (sc * xc) * w;
       } else {
         w -= cb * xc;
-        // ring columns of this launch: ii = i0 + i; ii = 0 is W_c (xc), ii = 1 is W_p (xp)
-        VF u[DCH];
-#pragma unroll
-        for (int i = 0; i < DCH; ++i)
-          if (i < rc) {
-            const int ii = i0 + i;
-            u[i] = (ii == 0) ? xc
-                             : ((ii == 1) ? xp
-                                          : stream_load<LP>((const VF *)(U0 + (int64_t)ring_slot(j - ii, S) * slot_stride + ro)));
-          }
         if (PASS == PASS_DOTS) {
+          if (RC > 0) dacc[0] += xc * w;
+          if (RC > 1) dacc[1] += xp * w;
 #pragma unroll
-          for (int i = 0; i < DCH; ++i)
-            if (i < rc) dacc[i] += u[i] * w;
+          for (int i = 2; i < RC; ++i) dacc[i] += u[i - 2] * w;
         } else {
+          if (RC > 0) w -= gm[0] * xc;
+          if (RC > 1) w -= gm[1] * xp;
 #pragma unroll
-          for (int i = 0; i < DCH; ++i)
-            if (i < rc) w -= *(const VF *)(gl + i * PW + cl * V) * u[i];
-          stream_store<SP>((VF *)(wn + ro), w);
+          for (int i = 2; i < RC; ++i) w -= gm[i] * u[i - 2];
+          stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += w * w;
           accx += w * xc;
         }
@@ -302,9 +304,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int64_t nblk = gridDim.x;
   if (PASS == PASS_DOTS) {
 #pragma unroll
-    for (int i = 0; i < DCH; ++i)
-      if (i < rc)
-        block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+    for (int i = 0; i < RC; ++i)
+      block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
   } else {
     block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
     if (PASS == PASS_UPDATE && xt)
