@@ -763,12 +763,12 @@ static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nbl
   int per_xcd = std::min(std::max(8, num_cus * per_cu_a / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   per_xcd = std::max(per_xcd, 1);
   *nblkA = 8 * per_xcd;
-  // fused dots/update passes (62-96 VGPRs depending on the ring-column count: 2 or 3 workgroups fit a CU):
-  // one round of 2 workgroups per CU. More rows in flight evict each other's gather halo (dots pass 36.3 ms
-  // per 30 launches at 2/CU, 37.6 at 4, 41.3 at 3, 43.6 at 6), and a grid that is not a multiple of what is
-  // resident leaves a ragged second round (update pass at r = 0: 37.3 at 2/CU, 42.5 at 4).
-  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 2));
-  int per_xcd_u = std::min(std::max(8, num_cus * per_cu_u / NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
+  // fused dots/update passes: 2 workgroups resident per CU (LDS padding, enqueue_run) and a grid of 2 per CU
+  // per panel. More rows in flight evict each other's gather halo
+  // (dots pass, r = 3, per 30 launches: 36.3 ms at 2 resident, 41.3 at 3), and a grid that is not a multiple
+  // of what is resident leaves a ragged last round. Panels run one after the other (panel-major dispatch).
+  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 2));  // per panel
+  int per_xcd_u = std::min(std::max(8, num_cus * per_cu_u) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   *nblkU = 8 * std::max(per_xcd_u, 1);
   int s = std::min(std::max(1, num_cus * per_cu_s / NP), (n + rows_per_block - 1) / rows_per_block);
   *nblkS = std::max(s, 1);
@@ -913,10 +913,20 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 // raise their limit once, outside any stream capture.
 template <typename F, int L> static hipError_t raise_lds_limits() {
   hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)  // SLQ_ALPHA_LDS_PAD experiments
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // fused passes: LDS padding caps their residency (SLQ_ALPHA_LDS_PAD experiments; dots/update: 2 per CU)
+  const void *fused_fns[] = {
+      (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>,  (const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 3>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 3>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4>};
+  for (const void *fn : fused_fns)
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kFusedMaxR>,
                              (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kFusedMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kFusedMaxR>,
                              (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kFusedMaxR>};
@@ -1174,7 +1184,7 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
     } else {                                                                                         \
       const bool half = PASS == PASS_ALPHA && op->rowptr_u != nullptr;                               \
       switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                       \
-        case 0: CSR_PASS_RC(PASS, LP, 0, LDS, XT); break;                                            \
+        case 0: CSR_PASS_RC(PASS, LP, (PASS == PASS_DOTS ? 1 : 0), LDS, XT); break;                  \
         case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                 \
         case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                 \
         case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                 \
@@ -1185,6 +1195,12 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       // alpha pass: residency is set by its grid (nblkF, slq_plan_create); SLQ_ALPHA_LDS_PAD can cap it
       // further with LDS padding (experiments)
       const size_t ldsA = lds0 + (tiled ? 0 : (size_t)env_int("SLQ_ALPHA_LDS_PAD", 0));
+      // dots/update passes: 64 KiB of LDS padding pins residency at 2 workgroups per CU whatever the variant's
+      // register count (62-96 VGPRs would admit 3 for some). Their grid is 2 per CU *per panel*: blocks are
+      // dispatched panel-major, so panel 0 fills the chip, panel 1 follows as its workgroups retire, and an
+      // XCD's L2 holds one panel's gather halo at a time (both panels side by side fetch 9.2/10.8 GB per
+      // dots/update launch instead of 6.5/8.6 GB).
+      const size_t fused_pad = tiled ? 0 : (size_t)env_int("SLQ_FUSED_LDS_PAD", 65536);
       // cross term: the update pass of the previous step left W_c.W_p behind, so this alpha pass skips W_p
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
       const int xt_u = (!tiled && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0;
@@ -1192,12 +1208,12 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkF, j, xt_a));
       if (r > 0) {
-        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0, 0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0, 0); });
+        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0 + fused_pad, 0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0 + fused_pad, 0); });
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
                                     p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
       }
-      const size_t ldsU = lds0 + (tiled ? (size_t)r * p->PW * p->esz : 0);  // the tiled kernel stages gamma in LDS
+      const size_t ldsU = lds0 + fused_pad + (tiled ? (size_t)r * p->PW * p->esz : 0);  // the tiled kernel stages gamma in LDS
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
                { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_u); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_u); });
 #undef CSR_PASS
