@@ -5,7 +5,6 @@ for `primate._lanczos.lanczos` (src/primate/_lanczos.cpp:88-99).
 
 from __future__ import annotations
 
-import ctypes as C
 from typing import Any, Optional, Union
 
 import numpy as np

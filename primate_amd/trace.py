@@ -18,7 +18,6 @@ from .estimators import (
 	MeanEstimator,
 	convergence_criterion,
 )
-from .linalg import update_trinv
 from .operators import is_valid_operator
 from .random import isotropic
 
