@@ -120,6 +120,17 @@ def hutchpp(
 		return 0.0 if not full else (0.0, EstimatorResult())
 	nb = (N // 3) if m is None else m
 	nb += nb % 3
+	from .operators import MatrixFunction
+
+	if isinstance(A, MatrixFunction) and A._builtin is not None and A.dtype == np.float64 and not A._stale_ring and 0 < nb <= N:
+		rng_ests, defl_ests = _hutchpp_device(A, nb, mode, draw)
+		est = np.sum(rng_ests) + (1 / nb) * np.sum(defl_ests)
+		if not full:
+			return est
+		result = EstimatorResult()
+		result.estimate, result.nit = est, 2 * nb
+		result.samples = np.concatenate([np.ravel(rng_ests), np.ravel(defl_ests)])
+		return result.estimate, result
 	W = draw(size=(N, nb)).astype(f_dtype)
 	Q = np.linalg.qr(A @ W, mode="reduced")[0]
 	if mode == "full":
@@ -140,6 +151,68 @@ def hutchpp(
 	result.nit = 2 * nb
 	result.samples = np.concatenate([np.ravel(rng_ests), np.ravel(defl_ests)])
 	return result.estimate, result
+
+
+def _hutchpp_device(A, nb: int, mode: str, draw: Callable, chunk: int = 128) -> tuple:
+	"""The body of `hutchpp` for a device `MatrixFunction` with every n x nb matrix resident in HBM
+	(src/primate/trace.py:160-176): Y = f(A) W by lock-step Lanczos batches, Q by CholeskyQR2 on the matrix
+	cores (Householder on the host if the sketch is numerically rank deficient), the nb quadratic forms of Q
+	by Lanczos quadrature (mode "reduced", as `A.quad`) or as diag(Q^T f(A) Q) (mode "full"), the deflation
+	G -= Q (Q^T G) as two tall-skinny products, and diag(G^T f(A) G). Probes come from the same NumPy stream
+	as the host path, so the two agree to rounding."""
+	from scipy.linalg import cholesky, solve_triangular
+
+	from . import engine
+
+	n = A.shape[0]
+	name, kw = A._builtin
+	ctx = A._op.ctx
+	Wd, Qd, Zd = (engine.DeviceMatrix(n, nb, ctx=ctx) for _ in range(3))
+
+	def apply_fun(src, dst):
+		for c in range(0, nb, chunk):
+			ns = min(chunk, nb - c)
+			plan = A._plan(ns, True)
+			plan.set_probes_device(src.col_ptr(c))
+			plan.run(A._rtol)
+			plan.fun_action_into(dst, c, name, **kw)
+
+	def column_dots(X, Y) -> np.ndarray:  # diag(X^T Y), block by block
+		out = np.empty(nb)
+		for c in range(0, nb, chunk):
+			ns = min(chunk, nb - c)
+			out[c : c + ns] = np.diag(X.tn(c, ns, Y, c, ns))
+		return out
+
+	try:
+		Wd.set(0, draw(size=(n, nb)))
+		apply_fun(Wd, Zd)  # Y = f(A) W
+		try:
+			R1 = cholesky(Zd.tn(0, nb, Zd, 0, nb), lower=False)
+			Wd.add_product(0, Zd, 0, solve_triangular(R1, np.eye(nb)), alpha=1.0, beta=0.0)  # W is free now
+			R2 = cholesky(Wd.tn(0, nb, Wd, 0, nb), lower=False)
+			Qd.add_product(0, Wd, 0, solve_triangular(R2, np.eye(nb)), alpha=1.0, beta=0.0)
+		except np.linalg.LinAlgError:
+			Qd.set(0, np.linalg.qr(Zd.get(0, nb), mode="reduced")[0])
+		if mode == "full":
+			apply_fun(Qd, Zd)
+			rng_ests = column_dots(Zd, Qd)
+		else:
+			rng_ests = np.empty(nb)
+			for c in range(0, nb, chunk):
+				ns = min(chunk, nb - c)
+				plan = A._plan(ns, False)
+				plan.set_probes_device(Qd.col_ptr(c))
+				plan.run(A._rtol)
+				rng_ests[c : c + ns] = plan.quadrature(name, **kw)
+		Wd.set(0, draw(size=(n, nb)))  # G
+		Wd.add_product(0, Qd, 0, Qd.tn(0, nb, Wd, 0, nb), alpha=-1.0, beta=1.0)
+		apply_fun(Wd, Zd)
+		defl_ests = column_dots(Zd, Wd)
+	finally:
+		for d in (Wd, Qd, Zd):
+			d.close()
+	return rng_ests, defl_ests
 
 
 def _xtrace_small(n: int, Wq: np.ndarray, H: np.ndarray, T: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:

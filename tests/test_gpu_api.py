@@ -327,3 +327,23 @@ def test_hutch_device_drawn_probes():
 	assert info.nit == 96
 	exact = np.sum(np.log(np.linalg.eigvalsh(L.toarray())))
 	assert abs(a - exact) / abs(exact) < 0.05
+
+
+def test_hutchpp_device_path_matches_host_algebra(monkeypatch):
+	"""hutchpp over a device MatrixFunction keeps its sketches in HBM; same probes (NumPy stream), so it
+	equals the reference's host algebra (QR on the host, A @ G through _matmat) to rounding."""
+	import primate_amd.trace as T
+	from primate_amd.operators import MatrixFunction
+
+	L = laplacian_2d(26)
+	M = MatrixFunction(L, fun="exp", deg=20, orth=5, t=-0.3)
+	exact = np.sum(np.exp(-0.3 * np.linalg.eigvalsh(L.toarray())))
+	for mode in ("reduced", "full"):
+		dev, info = T.hutchpp(M, m=45, mode=mode, seed=5, full=True)
+		with monkeypatch.context() as mp:
+			mp.setattr(T, "_hutchpp_device", None)  # the host path must not need it
+			mp.setattr(M, "_builtin", None)  # host algebra: QR and deflation in NumPy
+			host = T.hutchpp(M, m=45, mode=mode, seed=5)
+		assert info.nit == 90 and info.samples.shape == (90,)
+		assert dev == pytest.approx(host, rel=1e-9), mode
+		assert abs(dev - exact) / exact < 2e-2
