@@ -139,6 +139,31 @@ def test_oracle_random_graph_ragged(oracle, eng, dtype, rtol, orth):
 		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"{fun} orth={orth}")
 
 
+@pytest.mark.parametrize("orth", [1, 2, 4, 5, 6])
+def test_every_ring_column_count(oracle, eng, orth):
+	"""The fused passes are specialised on the number of ring columns (1..4) and hand over to the
+	store-and-revisit sweeps from r = 5 on, in the middle of a run: every variant and the switch-over."""
+	A = random_spd_graph(1234, 7.0, seed=orth)
+	rng = np.random.default_rng(orth)
+	for dtype, rtol in [(np.float64, 1e-10), (np.float32, 3e-4)]:
+		Ad = A.astype(dtype)
+		X = np.asfortranarray(rng.standard_normal((A.shape[0], 70)).astype(dtype))
+		op = eng.DeviceOperator(Ad)
+		got = eng.quad_batch(op, X, 16, orth, fun="exp", t=-0.1)
+		ref = oracle.quad_batch(Ad, X, 16, orth, fun="exp", t=-0.1, fresh_q=True, prefer="csr")
+		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"{dtype.__name__} orth={orth}")
+		if dtype == np.float64:
+			plan = eng.LanczosPlan(op, 70, 16, orth)
+			plan.set_probes(X)
+			plan.run()
+			a, b, steps = plan.tridiag()
+			ar, br, Qr = np.zeros(17), np.zeros(17), np.zeros((A.shape[0], max(orth, 2)), order="F")
+			oracle.lanczos(A, X[:, 33].copy(), 16, 1e-8, orth, ar, br, Qr)
+			np.testing.assert_allclose(a[33][:16], ar[:16], rtol=1e-9, atol=1e-11)
+			np.testing.assert_allclose(b[33][1:16], br[1:16], rtol=1e-9, atol=1e-11)
+		op.close()
+
+
 @pytest.mark.parametrize("nprobes", [1, 2, 15, 16, 17, 64, 129, 300])
 def test_probe_count_edges(oracle, eng, nprobes):
 	## every panel geometry (PW = 16..128, one or several panels, ragged last panel)
