@@ -80,6 +80,7 @@ struct slq_operator {
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
   void *vals_u = nullptr;
   double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
+  int64_t nnz_u = 0;       // entries of the upper-triangle copy
 };
 
 struct ProfEvent {
@@ -103,6 +104,7 @@ struct slq_plan {
   double *part;
   int nblkA, nblkS, nblkU, nblkT;  // grids: SpMM, streaming sweeps, fused dots/update passes, tiled passes
   int nblkF;                       // grid of the fused alpha pass
+  size_t alpha_pad;                // LDS padding that caps its residency
   double *quad_d, *nodes_d, *weights_d;
   int *fail_d;
   int rmax;
@@ -477,6 +479,9 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     if (pe == hipSuccess) pe = hipMemcpyAsync(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
   }
+  if (env_int("SLQ_DEBUG", 0) != 0)
+    fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=%d rms in-chunk |i-j| = %.1f\n", (long long)n, (long long)nnz,
+            op->perm_h ? 1 : 0, op->rms_dist);
   hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&op->colind, std::max<size_t>((size_t)nnz * 4, 4));
   if (e == hipSuccess) e = hipMalloc(&op->vals, std::max<size_t>((size_t)nnz * es, 8));
@@ -499,6 +504,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
                                 : build_symmetric_upper<float>(n, rowptr, colind, (const float *)vals, urp, uci, uva);
     if (sym) {
       const size_t nu = uci.size();
+      op->nnz_u = (int64_t)nu;
       hipError_t ue = hipMalloc((void **)&op->rowptr_u, (size_t)(n + 1) * 4);
       if (ue == hipSuccess) ue = hipMalloc((void **)&op->colind_u, std::max<size_t>(nu * 4, 4));
       if (ue == hipSuccess) ue = hipMalloc(&op->vals_u, std::max<size_t>(nu * es, 8));
@@ -833,16 +839,24 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
   {
-    // Fused alpha pass: one read sweep plus the gathers, latency-bound at 2 workgroups per CU. With the
-    // halo of the in-flight rows inside the XCD's L2 (2-D grid: rms in-chunk |i-j| = 632) 4 per CU is 25 %
-    // faster (0.88 -> 0.5 ms on configs[1]); on 3-D grids (rms > 1024 even after reordering) and random
-    // graphs the extra rows in flight evict each other's halo and 2 per CU stays best.
-    const int local = op->kind == OP_CSR && op->rms_dist >= 0.0 && op->rms_dist <= 1024.0;
-    const int per_cu_f = std::max(1, env_int("SLQ_BLOCKS_PER_CU_ALPHA", local ? 4 : 2));
+    // Fused alpha pass: one read sweep plus the gathers. Two regimes, told apart by the
+    // gathers per row of the matrix the pass walks (upper triangle when the operator is symmetric):
+    //  * <= 3 (5-point stencil, upper triangle): each wave has too few loads in flight, the pass is bound by
+    //    the rowptr -> colind -> gather latency chain: 4 workgroups per CU in total, panels side by side
+    //    (configs[1]: 0.88 ms at 2 per CU, 0.51 at 4; one panel at a time with 4 resident 0.61);
+    //  * more (full 5-point rows: 0.92 ms at 2 per CU vs 0.96 at 4; 7-point upper triangle: 0.67 vs 0.83;
+    //    random graphs): the waves carry enough loads and extra rows in flight only evict each other's halo
+    //    from the XCD's L2: 2 resident per CU (LDS padding), 2 per CU *per panel*, panel after panel.
+    const double gathers = op->kind != OP_CSR ? 0.0 : (double)(op->rowptr_u ? op->nnz_u : op->nnz) / (double)std::max<int64_t>(op->n, 1);
+    const int local = op->kind == OP_CSR && gathers <= 3.2;
+    const int per_cu_env = env_int("SLQ_BLOCKS_PER_CU_ALPHA", 0);  // total over the panels
     const int rows_per_block = kWaves * (64 / p->LPR);
     const int chunk = (p->n + 7) / 8;
-    const int per_xcd = std::min(std::max(8, ctx->num_cus * per_cu_f / p->NP) / 8, (chunk + rows_per_block - 1) / rows_per_block);
+    const int per_panel = per_cu_env > 0 ? std::max(8, ctx->num_cus * per_cu_env / p->NP)
+                                         : (local ? std::max(8, ctx->num_cus * 4 / p->NP) : ctx->num_cus * 2);
+    const int per_xcd = std::min(per_panel / 8, (chunk + rows_per_block - 1) / rows_per_block);
     p->nblkF = 8 * std::max(per_xcd, 1);
+    p->alpha_pad = (size_t)env_int("SLQ_ALPHA_LDS_PAD", (per_cu_env > 0 || local) ? 0 : 65536);
   }
   {
     // tiled passes: 1 workgroup per CU resident (8 wave-private LDS images), one panel at a time
@@ -1192,9 +1206,8 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
       }                                                                                              \
     }                                                                                                \
   } while (0)
-      // alpha pass: residency is set by its grid (nblkF, slq_plan_create); SLQ_ALPHA_LDS_PAD can cap it
-      // further with LDS padding (experiments)
-      const size_t ldsA = lds0 + (tiled ? 0 : (size_t)env_int("SLQ_ALPHA_LDS_PAD", 0));
+      // alpha pass: grid and residency cap (nblkF, alpha_pad) are chosen in slq_plan_create
+      const size_t ldsA = lds0 + (tiled ? 0 : p->alpha_pad);
       // dots/update passes: 64 KiB of LDS padding pins residency at 2 workgroups per CU whatever the variant's
       // register count (62-96 VGPRs would admit 3 for some). Their grid is 2 per CU *per panel*: blocks are
       // dispatched panel-major, so panel 0 fills the chip, panel 1 follows as its workgroups retire, and an
