@@ -81,6 +81,7 @@ struct slq_operator {
   void *vals_u = nullptr;
   double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
   int64_t nnz_u = 0;       // entries of the upper-triangle copy
+  double far_per_row = 0.0;  // stored nonzeros per row with |i - j| > 4096 (0 when unknown: device-resident CSR)
 };
 
 struct ProfEvent {
@@ -479,9 +480,17 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     if (pe == hipSuccess) pe = hipMemcpyAsync(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
   }
+  {
+    // gathers per row that reach further than any cache-resident halo (|i - j| > 4096 rows in the stored
+    // order): what decides between the recompute passes and the store-and-revisit sweeps (enqueue_run)
+    int64_t far = 0;
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) far += std::llabs((long long)colind[q] - (long long)i) > 4096;
+    op->far_per_row = (double)far / (double)n;
+  }
   if (env_int("SLQ_DEBUG", 0) != 0)
-    fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=%d rms in-chunk |i-j| = %.1f\n", (long long)n, (long long)nnz,
-            op->perm_h ? 1 : 0, op->rms_dist);
+    fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=%d rms in-chunk |i-j| = %.1f, far gathers per row %.2f\n", (long long)n,
+            (long long)nnz, op->perm_h ? 1 : 0, op->rms_dist, op->far_per_row);
   hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&op->colind, std::max<size_t>((size_t)nnz * 4, 4));
   if (e == hipSuccess) e = hipMalloc(&op->vals, std::max<size_t>((size_t)nnz * es, 8));
@@ -1145,7 +1154,8 @@ static int quadrature_lanes(int deg) {
 }
 
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
-static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
+static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
+  const bool fused = fused_mode != 0;
   hipStream_t st = p->ctx->stream;
   const int bp = p->bpad, deg = p->deg, S = p->S;
   const double eps = p->dtype == SLQ_F64 ? std::numeric_limits<double>::epsilon()
@@ -1171,7 +1181,13 @@ static int enqueue_run(slq_plan *p, double rtol, bool fused, bool nt) {
     // used when stale ring columns take part, whose projections are NOT small, so block-CGS and the
     // reference's MGS would differ at second order (1e-6..1e-5 measured with 18 stale vectors)
     const bool mgs = p->nstale > 0 || env_int("SLQ_MGS", 0) != 0;
-    if (op->kind == OP_CSR && fused && r <= kFusedMaxR && !mgs) {
+    // Recomputing the SpMM in every pass pays while the gathers are served from cache. A row whose
+    // neighbours are scattered over the whole vector (random graph, 16 per row) pays an HBM row fetch per
+    // gather and per pass: there the sweeps that gather once and store are 1.3-1.55x faster (configs[2]:
+    // 0.59 -> 0.38 s at orth 3), while grids keep the passes even in natural 3-D order (2 far gathers per row:
+    // 135 vs 178 ms). SLQ_FUSED=2 forces the passes.
+    const bool gathers_cached = fused_mode == 2 || op->far_per_row <= 4.0;
+    if (op->kind == OP_CSR && fused && gathers_cached && r <= kFusedMaxR && !mgs) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
@@ -1316,7 +1332,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
   HIP_TRY(hipSetDevice(p->ctx->device));
   hipStream_t st = p->ctx->stream;
-  const bool fused = env_int("SLQ_FUSED", 1) != 0;  // recompute-SpMM passes (default) vs store-and-revisit sweeps
+  const int fused = env_int("SLQ_FUSED", 1);  // 1: recompute-SpMM passes where they pay, 0: store-and-revisit sweeps, 2: passes always
   const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
   // The launch sequence of a run (7 launches per Lanczos step, ~210 for k = 30) depends only on
   // the plan, so it is captured into a hipGraph once and replayed: launch-bound for small n,
@@ -1326,7 +1342,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!graph_ok) {
     SLQ_TRY(enqueue_run(p, rtol, fused, nt));
   } else {
-    const int variant = (fused ? 1 : 0) | (nt ? 2 : 0) | (p->nstale << 2);
+    const int variant = fused | (nt ? 4 : 0) | (p->nstale << 3);
     if (!p->graph_exec || p->graph_rtol != rtol || p->graph_variant != variant) {
       if (p->graph_exec) {
         HIP_TRY(hipGraphExecDestroy(p->graph_exec));
