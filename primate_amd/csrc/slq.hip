@@ -1041,10 +1041,19 @@ extern "C" int slq_plan_generate_probes(slq_plan *p, int pdf, uint64_t seed, uin
   const int items = (p->n + (pdf == 0 ? 127 : 1)) / (pdf == 0 ? 128 : 2);
   const int gx = std::max(1, std::min(p->ctx->num_cus * 8, (items + 4 * RPW - 1) / (4 * RPW)));
   dim3 g(gx, p->NP);
+  if (p->op->perm_d) {
+    // stored row order differs from the caller's: element-wise generator, same (seed, id, row) stream
+    dim3 gp(std::max(1, std::min(p->ctx->num_cus * 8, (p->n + 4 * RPW - 1) / (4 * RPW))), p->NP);
+    PROFILED(p, SLQ_K_PROBES,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_gen_probes_perm<F, L><<<gp, dim3(256), 0, st>>>(p->n, (F *)slot_ptr(p, 0), pdf == SLQ_PDF_RADEMACHER ? 0 : 1,
+                                                                         seed, probe_offset, p->nprobes, p->op->perm_d))));
+  } else {
   PROFILED(p, SLQ_K_PROBES,
            DISPATCH(p->dtype, p->LPR,
                     (k_gen_probes<F, L><<<g, dim3(256), 0, st>>>(p->n,
                                         (F *)slot_ptr(p, 0), pdf, seed, probe_offset, p->nprobes))));
+  }
   p->pdf_sphere = (pdf == SLQ_PDF_SPHERE);
   return init_from_probes(p, p->pdf_sphere);
 }

@@ -1005,6 +1005,47 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // block serves 128 consecutive rows (Rademacher: 1 bit each) or 2 rows (normal: Box-Muller on two
 // 53-bit uniforms). Padding columns (id >= nprobes) are zero.
 //   Rademacher support is exactly {-1,+1} (reference: floor(2u)*2-1, src/primate/random.py:22-29).
+// One element of the same stream: probe `id`, caller row `row`. Used when the operator is stored in a
+// permuted row order, so that the probes - seen in the caller's order - do not depend on that choice.
+template <typename F>
+__device__ __forceinline__ F probe_element(int pdf, uint32_t k0, uint32_t k1, uint64_t id, int row) {
+  uint32_t r[4];
+  if (pdf == 0) {
+    philox4x32_10((uint32_t)(row >> 7), 0u, (uint32_t)id, (uint32_t)(id >> 32), k0, k1, r);
+    const int b = row & 127;
+    return ((r[b >> 5] >> (b & 31)) & 1u) ? (F)1 : (F)-1;
+  }
+  philox4x32_10((uint32_t)(row >> 1), 1u, (uint32_t)id, (uint32_t)(id >> 32), k0, k1, r);
+  const double u1 = ((double)(((uint64_t)r[0] << 21) ^ (r[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(((uint64_t)r[2] << 21) ^ (r[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincos(6.283185307179586476925 * u2, &sn, &cs);
+  return (F)(rad * ((row & 1) ? sn : cs));
+}
+
+// Generator for an operator stored as P A P^T: panel row i holds caller row perm[i].
+template <typename F, int LPR>
+__global__ __launch_bounds__(256) void k_gen_probes_perm(int n, F *W, int pdf, uint64_t seed, uint64_t probe_offset,
+                                                         int nprobes, const int32_t *__restrict__ perm) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int col0 = panel * PW + cl * V;
+  F *dst = W + ((int64_t)panel * n) * PW + cl * V;
+  for (int i = (blockIdx.x * 4 + wave) * RPW + g; i < n; i += gridDim.x * 4 * RPW) {
+    const int row = perm[i];
+    VF x;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      x[v] = (col0 + v < nprobes) ? probe_element<F>(pdf, k0, k1, probe_offset + (uint64_t)(col0 + v), row) : (F)0;
+    *(VF *)(dst + (int64_t)i * PW) = x;
+  }
+}
+
 template <typename F, int LPR>
 __global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64_t seed,
                                                     uint64_t probe_offset, int nprobes) {

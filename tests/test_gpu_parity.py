@@ -478,6 +478,17 @@ def test_opt_in_row_reordering_is_transparent(oracle, eng, monkeypatch):
 	numer, denom, _, cnt = acc.get()
 	np.testing.assert_allclose(numer, np.sum((A @ X) * X, axis=1), rtol=1e-9, atol=1e-9)
 	np.testing.assert_allclose(denom, np.sum(X * X, axis=1), rtol=1e-12)
+	## device-drawn probes are a function of (seed, probe id, CALLER row): the same with and without reordering
+	op0 = eng.DeviceOperator(A)
+	plan0 = eng.LanczosPlan(op0, 9, 20, 3)
+	plan3 = eng.LanczosPlan(op, 9, 20, 3)
+	for pdf in ("rademacher", "normal", "sphere"):
+		plan0.generate_probes(pdf, seed=77, probe_offset=5)
+		plan3.generate_probes(pdf, seed=77, probe_offset=5)
+		assert np.array_equal(plan0.get_probes(), plan3.get_probes()), pdf
+		plan0.run()
+		plan3.run()
+		np.testing.assert_allclose(plan3.quadrature("log"), plan0.quadrature("log"), rtol=1e-10)
 
 
 def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, monkeypatch):
