@@ -238,6 +238,13 @@ int slq_quad_batch(slq_context *ctx, slq_operator *op, const void *X, int64_t ld
                    int orth, int fun_id, const double *fun_params, double *quad_out,
                    double *nodes_out, double *weights_out);
 
+/* Y[:, i] = f(A) X[:, i] for nvec columns in one call: the batched counterpart of
+ * MatrixFunction._matvec (src/primate/operators.py:102-124: Lanczos with the full basis kept,
+ * eigh_tridiagonal, Q (Y (f(theta) * Y[0,:])) ||x||). X, Y: host column-major, operator dtype. Built-in
+ * fun ids only. Columns are processed in as few lock-step batches as the free device memory allows. */
+int slq_fAv_batch(slq_context *ctx, slq_operator *op, const void *X, int64_t ldx, int nvec, int deg,
+                  double rtol, int orth, int fun_id, const double *fun_params, void *Y, int64_t ldy);
+
 /* Single-vector drop-in for primate._lanczos.lanczos (src/primate/_lanczos.cpp:88-99), host
  * pointers, same in/out contract: v (n) is scratch and is clobbered; alpha, beta (deg+1) and
  * Q (n x ncv column-major) are written in place; beta[0] = 0. Q's incoming contents take part in

@@ -90,6 +90,7 @@ _SIGNATURES = {
 	"slq_plan_profile_enable": (C.c_int, [_P, C.c_int]),
 	"slq_plan_profile_read": (C.c_int, [_P, C.POINTER(SlqProfile), C.c_int]),
 	"slq_quad_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, _P, _P]),
+	"slq_fAv_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, C.c_int64]),
 	"slq_lanczos_f64": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, _P, C.c_size_t]),
 	"slq_lanczos_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_size_t]),
 }  # fmt: skip

@@ -1964,6 +1964,44 @@ extern "C" int slq_quad_batch(slq_context *ctx, slq_operator *op, const void *X,
   return rc;
 }
 
+extern "C" int slq_fAv_batch(slq_context *ctx, slq_operator *op, const void *X, int64_t ldx, int nvec, int deg,
+                             double rtol, int orth, int fun_id, const double *fun_params, void *Y, int64_t ldy) {
+  if (!ctx || !op || !X || !Y) return fail(SLQ_EINVAL, "ctx/op/X/Y is NULL");
+  if (nvec <= 0) return fail(SLQ_EINVAL, "nvec must be positive");
+  if (ldx < op->n || ldy < op->n) return fail(SLQ_EINVAL, "ldx/ldy < n");
+  int d = deg, o = orth;
+  SLQ_TRY(normalise_params(op->n, &d, &o));
+  // the whole basis of every column is kept (deg + 1 panels): chunk the columns to the free device memory
+  size_t free_b = 0, total_b = 0;
+  SLQ_TRY(slq_context_meminfo(ctx, &free_b, &total_b));
+  int chunk = nvec;
+  for (;;) {
+    size_t need = 0;
+    SLQ_TRY(slq_plan_query_bytes(op->dtype, op->n, chunk, d, o, 1, &need));
+    if (need + ((size_t)1 << 30) <= free_b || chunk <= 8) break;
+    chunk = (chunk + 1) / 2;
+  }
+  const size_t es = esize(op->dtype);
+  int rc = SLQ_OK;
+  slq_plan *p = nullptr;
+  int plan_cols = 0;
+  for (int c0 = 0; c0 < nvec && rc == SLQ_OK; c0 += chunk) {
+    const int nc = std::min(chunk, nvec - c0);
+    if (nc != plan_cols) {
+      if (p) slq_plan_destroy(p);
+      p = nullptr;
+      rc = slq_plan_create(ctx, op, nc, d, o, 1, &p);
+      plan_cols = nc;
+      if (rc != SLQ_OK) break;
+    }
+    rc = slq_plan_set_probes(p, (const char *)X + (size_t)c0 * (size_t)ldx * es, ldx);
+    if (rc == SLQ_OK) rc = slq_plan_run(p, rtol);
+    if (rc == SLQ_OK) rc = slq_plan_fun_action(p, fun_id, fun_params, (char *)Y + (size_t)c0 * (size_t)ldy * es, ldy);
+  }
+  if (p) slq_plan_destroy(p);
+  return rc;
+}
+
 template <typename F>
 static int lanczos_single(slq_context *ctx, slq_operator *op, F *v, int deg, F rtol, int orth, F *alpha,
                           F *beta, F *Q, size_t ncv) {

@@ -299,6 +299,8 @@ def quad_batch(
 		X = np.asarray(X)
 		X = X.reshape(-1, 1) if X.ndim == 1 else X
 		X = np.asfortranarray(X, dtype=op.dtype)
+		if X.shape[0] != n:
+			raise ValueError(f"X has {X.shape[0]} rows, the operator has {n}")
 		nprobes = X.shape[1]
 	quad = np.zeros(nprobes)
 	nodes = np.zeros((nprobes, deg_eff)) if return_rule else None
@@ -311,6 +313,24 @@ def quad_batch(
 		raise op.error
 	check(rc)
 	return (quad, nodes, weights) if return_rule else quad
+
+
+def fun_action_batch(op: DeviceOperator, X: np.ndarray, deg: int, orth: int = 0, fun="identity", rtol: float = 1e-8, **fun_kwargs) -> np.ndarray:
+	"""Y = f(A) X for all columns of X in one call (C-ABI slq_fAv_batch): the batched form of
+	`MatrixFunction._matvec` (src/primate/operators.py:102-124)."""
+	fid, params = fun_spec(fun, **fun_kwargs)
+	assert fid is not None, "fun_action_batch takes built-in function names"
+	X = np.asarray(X)
+	X = np.asfortranarray(X.reshape(-1, 1) if X.ndim == 1 else X, dtype=op.dtype)
+	n = op.shape[0]
+	if X.shape[0] != n:
+		raise ValueError(f"X has {X.shape[0]} rows, the operator has {n}")
+	Y = np.zeros((n, X.shape[1]), dtype=op.dtype, order="F")
+	rc = _capi.lib().slq_fAv_batch(op.ctx._h, op._h, ptr(X), n, X.shape[1], int(deg), float(rtol), int(orth), fid, ptr(params), ptr(Y), n)
+	if rc == _capi.SLQ_ECALLBACK and getattr(op, "error", None) is not None:
+		raise op.error
+	check(rc)
+	return Y
 
 
 def quadrature_batch(d: np.ndarray, e: np.ndarray, fun=None, ctx: Optional[Context] = None, **fun_kwargs):

@@ -267,6 +267,26 @@ def test_fun_action_against_dense_eigendecomposition(eng, golden):
 	np.testing.assert_allclose(plan.fun_action("exp", t=-0.1), golden["mf_matvec_exp_t"], rtol=1e-9, atol=1e-10)
 
 
+def test_one_call_fun_action_batch(eng, golden):
+	"""slq_fAv_batch: f(A) X for a block of columns in one FFI crossing, against the dense eigendecomposition
+	and against the plan-based route it wraps."""
+	L = random_spd_graph(90, 5.0, seed=4)  # distinct eigenvalues: no Lanczos breakdown before deg = n
+	n = L.shape[0]
+	rng = np.random.default_rng(2)
+	X = np.asfortranarray(rng.standard_normal((n, 11)))
+	w, U = np.linalg.eigh(L.toarray())
+	op = eng.DeviceOperator(L)
+	for fun, kw, f in [("exp", {"t": -0.2}, lambda x: np.exp(-0.2 * x)), ("inv", {}, lambda x: 1 / x), ("identity", {}, lambda x: x)]:
+		Y = eng.fun_action_batch(op, X, deg=n, orth=n, fun=fun, **kw)
+		np.testing.assert_allclose(Y, (U * f(w)) @ (U.T @ X), rtol=1e-7, atol=1e-8)
+	plan = eng.LanczosPlan(op, 11, 25, 5, keep_basis=True)
+	plan.set_probes(X)
+	plan.run()
+	np.testing.assert_allclose(eng.fun_action_batch(op, X, deg=25, orth=5, fun="exp", t=-0.2), plan.fun_action("exp", t=-0.2), rtol=1e-12, atol=1e-13)
+	with pytest.raises(ValueError):
+		eng.fun_action_batch(op, X[:5], deg=10)
+
+
 def test_standalone_quadrature_entry(eng, golden, oracle):
 	d, e = golden["tri_d"], golden["tri_e"]
 	nodes, weights = eng.quadrature_batch(d[None, :], e[None, :])
