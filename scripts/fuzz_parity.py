@@ -1,0 +1,76 @@
+"""Randomised parity sweep on the GPU box: random SPD graphs / grids, every panel geometry, orth 0..deg,
+both dtypes, against the CPU oracle on identical probes. Prints one line per failure and a summary.
+usage: python scripts/fuzz_parity.py [seconds] [seed]"""
+import sys, time
+from pathlib import Path
+import numpy as np, scipy.sparse as sp
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from conftest import laplacian_2d, laplacian_3d
+from oracle import oracle
+from primate_amd import engine as eng
+
+oracle.build()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+def random_spd(n, deg, rng):
+	m = int(n * deg / 2)
+	i, j = rng.integers(0, n, m), rng.integers(0, n, m)
+	W = sp.coo_matrix((rng.uniform(0.1, 1.0, m), (i, j)), shape=(n, n)).tocsr()
+	W = W + W.T
+	A = (sp.diags(np.asarray(abs(W).sum(axis=1)).ravel() + rng.uniform(0.05, 1.0, n)) - W).tocsr()
+	A.sort_indices()
+	return A
+
+t0 = time.time(); cases = fails = 0
+worst = 0.0
+while time.time() - t0 < budget:
+	kind = rng.integers(0, 4)
+	if kind == 0:
+		A = laplacian_2d(int(rng.integers(6, 60)))
+	elif kind == 1:
+		A = laplacian_3d(int(rng.integers(4, 14)))
+	else:
+		A = random_spd(int(rng.integers(30, 5000)), float(rng.uniform(1.0, 12.0)), rng)
+	n = A.shape[0]
+	dtype = np.float64 if rng.random() < 0.7 else np.float32
+	P = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 257]))
+	deg = int(rng.integers(1, min(n, 40) + 1))
+	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 8, deg]))
+	fun, kw = [("log", {}), ("exp", {"t": -0.1}), ("identity", {}), ("sqrt", {}), ("inv", {})][int(rng.integers(0, 5))]
+	Ad = A.astype(dtype)
+	X = np.asfortranarray((np.floor(rng.random((n, P)) * 2) * 2 - 1 if rng.random() < 0.5 else rng.standard_normal((n, P))).astype(dtype))
+	## near-breakdown runs (beta -> 0: small grids with repeated eigenvalues) amplify rounding by 1/beta in ANY
+	## implementation, and a zero Ritz value makes sqrt/log/inv a coin toss: compare only well-posed runs
+	al, be, Qr = np.zeros(deg + 1, dtype), np.zeros(deg + 1, dtype), np.zeros((n, max(orth, 2)), dtype, order="F")
+	steps = oracle.lanczos(Ad, X[:, 0].copy(), deg, 1e-8, min(orth, deg), al, be, Qr)
+	if steps < deg or (deg > 1 and np.min(np.abs(be[1:deg])) < 1e-3 * np.max(np.abs(be[1:deg]))):
+		continue
+	try:
+		op = eng.DeviceOperator(Ad)
+		got = eng.quad_batch(op, X, deg, orth, fun=fun, **kw)
+		ref = oracle.quad_batch(Ad, X, deg, orth, fun=fun, fresh_q=True, prefer="csr", **kw)
+		op.close()
+		err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))
+		tol = 1e-7
+		if dtype == np.float32:
+			## fp32 noise is amplified by log/inv of small Ritz values: the yardstick is how far the fp32 ORACLE is
+			## from the fp64 oracle on the same probes, not a fixed number
+			ref64 = oracle.quad_batch(A, X.astype(np.float64), deg, orth, fun=fun, fresh_q=True, prefer="csr", **kw)
+			noise = np.max(np.abs(ref - ref64) / np.maximum(np.abs(ref64), 1e-300))
+			err = np.max(np.abs(got - ref64) / np.maximum(np.abs(ref64), 1e-300))
+			tol = max(3e-4, 4.0 * noise)
+		bad = not np.all(np.isfinite(got) == np.isfinite(ref)) or not (err <= tol or not np.isfinite(err))
+		if np.isfinite(err):
+			worst = max(worst, err if dtype == np.float64 else 0.0)
+	except Exception as e:  # noqa: BLE001
+		bad, err = True, repr(e)
+	cases += 1
+	if bad:
+		fails += 1
+		print(f"FAIL kind={kind} n={n} nnz={A.nnz} dtype={dtype.__name__} P={P} deg={deg} orth={orth} fun={fun} err={err}", flush=True)
+	if cases % 50 == 0:
+		print(f"... {cases} cases, {fails} failures, worst fp64 rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {cases} cases, {fails} failures, worst fp64 rel err {worst:.2e}")
+sys.exit(1 if fails else 0)
