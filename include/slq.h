@@ -167,6 +167,12 @@ int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, con
                          int fun_id, const double *fun_params, double *quad, double *nodes,
                          double *weights);
 
+/* Full eigendecomposition of nb symmetric tridiagonals (eigh_tridiag / eigvalsh_tridiag,
+ * src/primate/tridiag.py:25-62; what rayleigh_ritz and MatrixFunction._matvec call): d, e as above
+ * (e[:,0] ignored). w: nb x deg ascending eigenvalues. Z: nb x deg x deg row-major, eigenvectors in the
+ * COLUMNS of each matrix, or NULL for eigenvalues only. deg <= 141 (eigenvectors live in LDS). */
+int slq_eigh_tridiag_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e, double *w, double *Z);
+
 /* Tall-skinny dense algebra for the exchangeable estimators (xtrace / hutch++: the host-side
  * np.linalg.qr, Q.T @ W, Z.T @ W, ... of src/primate/trace.py:160-176,199-227,296-302) on the matrix
  * cores (fp64 MFMA). Matrices are column-major n x cols with leading dimension n.
@@ -179,6 +185,10 @@ int slq_dmat_destroy(slq_dmat *m);
 int slq_dmat_set(slq_dmat *m, int c0, int nc, const double *host, int64_t ld);
 int slq_dmat_get(slq_dmat *m, int c0, int nc, double *host, int64_t ld);
 int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr);
+/* Isotropic probes straight into columns [c0, c0+nc): element (seed, probe id = probe_offset + column, row) of
+ * the same Philox stream as slq_plan_generate_probes; sphere columns have norm sqrt(n). The batch filler of
+ * src/primate/random.py:100-142 (class Isotropic) without a host array. */
+int slq_dmat_generate(slq_dmat *m, int c0, int nc, int pdf, uint64_t seed, uint64_t probe_offset);
 int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int nc); /* dst[:, d0:d0+nc] = src[:, s0:s0+nc], on the device */
 int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host);
 int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,

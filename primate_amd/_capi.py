@@ -79,6 +79,7 @@ _SIGNATURES = {
 	"slq_dmat_gemm_nn": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_double, C.c_double]),
 	"slq_plan_fun_action_dmat": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
 	"slq_plan_get_probes_dmat": (C.c_int, [_P, _P, C.c_int]),
+	"slq_dmat_generate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64]),
 	"slq_dmat_copy": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
 	"slq_measure_stream": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 	"slq_plan_set_probes_device": (C.c_int, [_P, _P, C.c_int64]),
@@ -90,6 +91,7 @@ _SIGNATURES = {
 	"slq_plan_profile_enable": (C.c_int, [_P, C.c_int]),
 	"slq_plan_profile_read": (C.c_int, [_P, C.POINTER(SlqProfile), C.c_int]),
 	"slq_quad_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, _P, _P]),
+	"slq_eigh_tridiag_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
 	"slq_fAv_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, C.c_int64]),
 	"slq_lanczos_f64": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, _P, C.c_size_t]),
 	"slq_lanczos_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_size_t]),

@@ -1667,6 +1667,19 @@ extern "C" int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr) {
   return SLQ_OK;
 }
 
+extern "C" int slq_dmat_generate(slq_dmat *m, int c0, int nc, int pdf, uint64_t seed, uint64_t probe_offset) {
+  SLQ_TRY(dmat_range(m, c0, nc, "slq_dmat_generate"));
+  if (pdf < 0 || pdf > 2) return fail(SLQ_EINVAL, "Invalid distribution id %d supplied.", pdf);
+  HIP_TRY(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  double *x = m->d + (size_t)c0 * m->n;
+  k_gen_cols<<<dim3((unsigned)((m->n + 255) / 256)), dim3(256), 0, st>>>(m->n, x, nc, pdf == SLQ_PDF_RADEMACHER ? 0 : 1, seed, probe_offset);
+  if (pdf == SLQ_PDF_SPHERE) k_scale_cols_sphere<<<dim3(nc), dim3(256), 0, st>>>(m->n, x);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return SLQ_OK;
+}
+
 extern "C" int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int nc) {
   SLQ_TRY(dmat_range(dst, d0, nc, "slq_dmat_copy(dst)"));
   SLQ_TRY(dmat_range(src, s0, nc, "slq_dmat_copy(src)"));
@@ -1834,6 +1847,39 @@ extern "C" int slq_fttr_batch(slq_context *ctx, int nb, int n, int k, const doub
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   hipFree(buf);
   if (e != hipSuccess) return fail(SLQ_EHIP, "slq_fttr_batch: %s", hipGetErrorString(e));
+  return SLQ_OK;
+}
+
+extern "C" int slq_eigh_tridiag_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e, double *w,
+                                      double *Z) {
+  if (!ctx || !d || !e || !w) return fail(SLQ_EINVAL, "ctx/d/e/w is NULL");
+  if (nb <= 0 || deg <= 0) return fail(SLQ_EINVAL, "bad batch size or degree");
+  const size_t lds = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8 + (size_t)deg * sizeof(int);
+  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip eigenvector solve", deg);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t in = (size_t)nb * deg, zz = Z ? in * deg : 0;
+  double *buf = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, (3 * in + zz + 1) * 8));
+  double *dd = buf, *de = dd + in, *dw = de + in, *dz = Z ? dw + in : nullptr;
+  int *dfail = (int *)(dw + in + zz);
+  hipError_t err = hipMemcpyAsync(dd, d, in * 8, hipMemcpyHostToDevice, st);
+  if (err == hipSuccess) err = hipMemcpyAsync(de, e, in * 8, hipMemcpyHostToDevice, st);
+  if (err == hipSuccess) err = hipMemsetAsync(dfail, 0, sizeof(int), st);
+  if (err == hipSuccess && lds > 48 * 1024)
+    err = hipFuncSetAttribute((const void *)k_eigh_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (err == hipSuccess) {
+    k_eigh_tridiag<<<dim3(nb), dim3(64), lds, st>>>(deg, dd, de, dw, dz, dfail);
+    err = hipGetLastError();
+  }
+  int bad = 0;
+  if (err == hipSuccess) err = hipMemcpyAsync(&bad, dfail, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipMemcpyAsync(w, dw, in * 8, hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess && Z) err = hipMemcpyAsync(Z, dz, zz * 8, hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipStreamSynchronize(st);
+  hipFree(buf);
+  if (err != hipSuccess) return fail(SLQ_EHIP, "slq_eigh_tridiag_batch: %s", hipGetErrorString(err));
+  if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one matrix");
   return SLQ_OK;
 }
 

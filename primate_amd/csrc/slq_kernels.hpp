@@ -1046,6 +1046,31 @@ __global__ __launch_bounds__(256) void k_gen_probes_perm(int n, F *W, int pdf, u
   }
 }
 
+// Column-major generator (stand-alone entry slq_dmat_generate): X[row, c] = element (seed, probe id0 + c, row)
+// of the same stream as the panel generators. One thread per row, columns walked in the loop.
+__global__ __launch_bounds__(256) void k_gen_cols(int64_t n, double *X, int nc, int pdf01, uint64_t seed, uint64_t id0) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int c = 0; c < nc; ++c) X[(int64_t)c * n + row] = probe_element<double>(pdf01, k0, k1, id0 + (uint64_t)c, (int)row);
+}
+
+// sphere probes: scale every column to norm sqrt(n) (src/primate/random.py:36-41). One workgroup per column.
+__global__ __launch_bounds__(256) void k_scale_cols_sphere(int64_t n, double *X) {
+  __shared__ double red[256];
+  double *x = X + (int64_t)blockIdx.x * n;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double scale = red[0] > 0.0 ? sqrt((double)n) / sqrt(red[0]) : 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) x[i] *= scale;
+}
+
 template <typename F, int LPR>
 __global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64_t seed,
                                                     uint64_t probe_offset, int nprobes) {
@@ -1249,30 +1274,12 @@ __global__ __launch_bounds__(64) void k_quadrature(StepState st, int lanes, int 
 }
 
 
-// ---- f(A)v coefficients: one wave per probe, full eigenvector matrix in LDS -----------------------
-// f(A) x ~= ||x|| Q Y (f(theta) * Y[0,:])   (reference: MatrixFunction._matvec,
-// src/primate/operators.py:118-124). With unnormalised ring vectors W_t = nu_t q_t this is
-// sum_t g_t W_t with g_t = ||x|| c_t / nu_t, c = Y (f(theta) * Y[0,:]).
-// All 64 lanes run the scalar QL recurrences redundantly (identical values, so the LDS writes to
-// d/e are the same from every lane); the plane rotations are applied lane-parallel, lane r owning
-// rows r, r+64, ... of Y. coef[t][col] = sign * g_t (0 where nu_t = 0, i.e. past an early stop);
-// reverse_rows stores g_t in row k-1-t, the order in which k_reorth_update walks the ring.
-__global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, double p0, double p1,
-                                                   double sign, int reverse_rows,
-                                                   double *__restrict__ coef,
-                                                   int *__restrict__ fail) {
-  extern __shared__ double lds[];
-  const int k = st.deg, ldz = k + 1;
-  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
-  const int lane = threadIdx.x, col = blockIdx.x;
-  for (int i = lane; i < k; i += 64) {
-    d[i] = st.alpha[(int64_t)i * st.bpad + col];
-    e[i] = (i + 1 < k) ? st.nu[(int64_t)(i + 1) * st.bpad + col] : 0.0;
-  }
-  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
-  __syncthreads();
-  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
-  __syncthreads();
+// Implicit QL with Wilkinson shifts on a symmetric tridiagonal (d, e: e[i] couples i and i+1) held in LDS,
+// accumulating the full eigenvector matrix Z (k x k, leading dimension ldz, identity on entry). Run by one
+// wave: every lane repeats the scalar recurrences (identical values, so the LDS writes to d/e agree) and the
+// plane rotations are applied lane-parallel, lane r owning rows r, r+64, ... of Z. Returns 1 if some
+// eigenvalue did not converge in 60 sweeps.
+__device__ __forceinline__ int ql_implicit_full(double *d, double *e, double *Z, int k, int ldz, int lane) {
   int bad = 0;
   for (int l = 0; l < k; ++l) {
     int iter = 0;
@@ -1323,6 +1330,34 @@ __global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, dou
       e[m] = 0.0;
     }
   }
+  return bad;
+}
+
+// ---- f(A)v coefficients: one wave per probe, full eigenvector matrix in LDS -----------------------
+// f(A) x ~= ||x|| Q Y (f(theta) * Y[0,:])   (reference: MatrixFunction._matvec,
+// src/primate/operators.py:118-124). With unnormalised ring vectors W_t = nu_t q_t this is
+// sum_t g_t W_t with g_t = ||x|| c_t / nu_t, c = Y (f(theta) * Y[0,:]).
+// All 64 lanes run the scalar QL recurrences redundantly (identical values, so the LDS writes to
+// d/e are the same from every lane); the plane rotations are applied lane-parallel, lane r owning
+// rows r, r+64, ... of Y. coef[t][col] = sign * g_t (0 where nu_t = 0, i.e. past an early stop);
+// reverse_rows stores g_t in row k-1-t, the order in which k_reorth_update walks the ring.
+__global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, double p0, double p1,
+                                                   double sign, int reverse_rows,
+                                                   double *__restrict__ coef,
+                                                   int *__restrict__ fail) {
+  extern __shared__ double lds[];
+  const int k = st.deg, ldz = k + 1;
+  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
+  const int lane = threadIdx.x, col = blockIdx.x;
+  for (int i = lane; i < k; i += 64) {
+    d[i] = st.alpha[(int64_t)i * st.bpad + col];
+    e[i] = (i + 1 < k) ? st.nu[(int64_t)(i + 1) * st.bpad + col] : 0.0;
+  }
+  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
+  __syncthreads();
+  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
+  __syncthreads();
+  const int bad = ql_implicit_full(d, e, Z, k, ldz, lane);
   __syncthreads();
   // e[i] <- f(theta_i) * Y[0,i]
   for (int i = lane; i < k; i += 64) e[i] = apply_fun(fun_id, p0, p1, d[i]) * Z[i];
@@ -1335,6 +1370,45 @@ __global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, dou
     const int row = reverse_rows ? (k - 1 - t) : t;
     coef[(int64_t)row * st.bpad + col] = (nu > 0.0) ? sign * xnorm * c / nu : 0.0;
   }
+  if (bad && lane == 0) atomicOr(fail, 1);
+}
+
+// Full eigendecomposition of a batch of symmetric tridiagonals (stand-alone entry slq_eigh_tridiag_batch;
+// reference: eigh_tridiag, src/primate/tridiag.py:25-44). One wave per matrix; din/ein are nb x k row-major with
+// ein[:, i] coupling i-1 and i (ein[:, 0] ignored); eigenvalues ascending into w (nb x k), eigenvectors as the
+// COLUMNS of Zout (nb x k x k, row-major per matrix) when Zout != null.
+__global__ __launch_bounds__(64) void k_eigh_tridiag(int k, const double *__restrict__ din, const double *__restrict__ ein,
+                                                     double *__restrict__ w, double *__restrict__ Zout, int *__restrict__ fail) {
+  extern __shared__ double lds[];
+  const int ldz = k + 1;
+  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
+  int *ord = (int *)(Z + (size_t)k * ldz);
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  for (int i = lane; i < k; i += 64) {
+    d[i] = din[b * k + i];
+    e[i] = (i + 1 < k) ? ein[b * k + i + 1] : 0.0;
+  }
+  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
+  __syncthreads();
+  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
+  __syncthreads();
+  const int bad = ql_implicit_full(d, e, Z, k, ldz, lane);
+  __syncthreads();
+  // ascending order by rank counting (ties broken by index): ord[rank] = source column
+  for (int i = lane; i < k; i += 64) {
+    int rank = 0;
+    const double di = d[i];
+    for (int t = 0; t < k; ++t) rank += (d[t] < di) || (d[t] == di && t < i);
+    ord[rank] = i;
+  }
+  __syncthreads();
+  for (int i = lane; i < k; i += 64) w[b * k + i] = d[ord[i]];
+  if (Zout)
+    for (int idx = lane; idx < k * k; idx += 64) {
+      const int row = idx / k, col = idx % k;
+      Zout[b * k * k + idx] = Z[row * ldz + ord[col]];
+    }
   if (bad && lane == 0) atomicOr(fail, 1);
 }
 

@@ -348,6 +348,20 @@ def quadrature_batch(d: np.ndarray, e: np.ndarray, fun=None, ctx: Optional[Conte
 	return (nodes, weights) if fun is None else (quad, nodes, weights)
 
 
+def eigh_tridiag_batch(d: np.ndarray, e: np.ndarray, vectors: bool = True, ctx: Optional[Context] = None):
+	"""Eigenvalues (ascending) and, optionally, eigenvectors (columns) of a batch of symmetric tridiagonals on
+	the device (slq_eigh_tridiag_batch). d, e: (nb, deg), e[:, 0] ignored."""
+	ctx = ctx or default_context()
+	d = np.ascontiguousarray(np.atleast_2d(d), dtype=np.float64)
+	e = np.ascontiguousarray(np.atleast_2d(e), dtype=np.float64)
+	assert d.shape == e.shape
+	nb, deg = d.shape
+	w = np.zeros((nb, deg))
+	Z = np.zeros((nb, deg, deg)) if vectors else None
+	check(_capi.lib().slq_eigh_tridiag_batch(ctx._h, nb, deg, ptr(d), ptr(e), ptr(w), ptr(Z)))
+	return (w, Z) if vectors else w
+
+
 def fttr_batch(theta: np.ndarray, alpha: np.ndarray, beta: np.ndarray, k: Optional[int] = None, ctx: Optional[Context] = None) -> np.ndarray:
 	"""FTTR quadrature weights on the device (slq_fttr_batch); rows are independent rules."""
 	ctx = ctx or default_context()
@@ -429,6 +443,11 @@ class DeviceMatrix:
 		p = C.c_void_p()
 		check(_capi.lib().slq_dmat_ptr(self._h, int(c0), C.byref(p)))
 		return p.value
+
+	def generate(self, c0: int, nc: int, pdf: str = "rademacher", seed: int = 0, probe_offset: int = 0):
+		"""Isotropic probes into columns [c0, c0+nc): the device Philox stream, probe ids probe_offset + column."""
+		assert pdf in _capi.PDF_IDS, f"Invalid distribution '{pdf}' supplied."
+		check(_capi.lib().slq_dmat_generate(self._h, int(c0), int(nc), _capi.PDF_IDS[pdf], int(seed), int(probe_offset)))
 
 	def copy_from(self, d0: int, src: "DeviceMatrix", s0: int, nc: int):
 		"""self[:, d0:d0+nc] = src[:, s0:s0+nc] (device to device)."""

@@ -148,6 +148,42 @@ class ConvergenceCriterion:
 		return "Composite convergence criterion"
 
 
+class ControlVariableEstimator(MeanEstimator):
+	"""Mean of a scalar response corrected by control variates with known expectations `ecv`
+	(src/primate/estimators.py:148-196): samples are rows [y, c_1, ..., c_m]; the estimate is
+	mean(y) - alpha . (mean(c) - ecv) with alpha = Cov(c)^-1 Cov(c, y) re-estimated at every update unless
+	given."""
+
+	def __init__(self, ecv, alpha=None, record: bool = False):
+		ecv = np.atleast_1d(ecv).astype(float).ravel()
+		super().__init__(len(ecv), covariance=False, record=record)
+		if alpha is not None:
+			alpha = np.atleast_1d(alpha).astype(float).ravel()
+			assert len(alpha) == len(ecv), "Coefficients alpha must have same length as the control variables."
+		self.alpha, self.ecv = alpha, ecv
+		self.cov = Covariance(dim=len(ecv) + 1)
+		self._fit_alpha = alpha is None
+
+	def update(self, samples):
+		self.cov.update(np.atleast_1d(samples))
+		self.n_samples = self.cov.n
+		if self._fit_alpha:
+			C = np.atleast_2d(self.cov(ddof=1))
+			self.alpha = np.atleast_1d(C[0, 1] / C[1, 1]) if self.cov.dim == 2 else np.linalg.solve(C[1:, 1:], C[1:, 0])
+		return self
+
+	@property
+	def estimate(self):
+		if self.n_samples == 0:
+			return np.nan
+		return float(self.cov.mu[0] - np.dot(self.alpha, self.cov.mu[1:] - self.ecv))
+
+
+def arr_summary(x) -> str:
+	"""Short printable form of an estimate (src/primate/estimators.py:18-32); used in the criteria messages."""
+	return _summary(x)
+
+
 def _summary(x) -> str:
 	if x is None:
 		return "None"

@@ -100,10 +100,9 @@ def rayleigh_ritz(A, deg: Optional[int] = None, return_eigenvectors: bool = Fals
 	res = lanczos(A, deg=deg, return_basis=want_Q, **kwargs)
 	(a, b), Q = res if want_Q else (res, None)
 	if return_eigenvectors:
-		## host LAPACK for the dense k x k eigenvector matrix: k^2 output, not on the hot path
-		from scipy.linalg import eigh_tridiagonal
+		from .tridiag import eigh_tridiag  # device QL (k <= 141: the k x k eigenvectors live in LDS)
 
-		rw, Y = eigh_tridiagonal(a, b)
+		rw, Y = eigh_tridiag(a, b)
 		return (rw, Y) if not want_Q else (rw, Y, Q)
 	rw, _ = quadrature(a, np.append([0], b))
 	return rw if not want_Q else (rw, Q)

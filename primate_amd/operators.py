@@ -177,13 +177,13 @@ class MatrixFunction(LinearOperator):
 		if self._builtin is not None:
 			name, kw = self._builtin
 			return plan.fun_action(name, **kw)
-		## Python callable: nodes/eigenvectors on the host (k x k per probe), basis from the device
-		from scipy.linalg import eigh_tridiagonal
-
+		## Python callable: it can only be evaluated on the host, so the k x k eigenvectors of every probe's T come
+		## back from the device eigensolver (one batched call) and the basis combination is done per probe
 		a, b, _ = plan.tridiag()
+		rws, Ys = engine.eigh_tridiag_batch(a[:, : self._deg], b[:, : self._deg], vectors=True, ctx=self._op.ctx)
 		out = np.zeros((self.shape[0], X.shape[1]), dtype=self.dtype, order="F")
 		for i in range(X.shape[1]):
-			rw, Y = eigh_tridiagonal(a[i, : self._deg], b[i, 1 : self._deg])
+			rw, Y = rws[i], Ys[i]
 			coef = Y @ (np.ravel(self._fun(rw)) * Y[0, :])
 			out[:, i] = np.linalg.norm(X[:, i]) * (plan.basis(i) @ coef)
 		return out

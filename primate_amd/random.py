@@ -10,6 +10,8 @@ Contract reproduced from src/primate/random.py:22-41,47-80 and pinned by tests/g
 
 from __future__ import annotations
 
+import concurrent.futures
+import multiprocessing
 from typing import Callable, Optional, Union
 
 import numpy as np
@@ -56,3 +58,89 @@ def isotropic(
 
 	_isotropic.pdf = pdf
 	return _isotropic if size is None else _isotropic(size)
+
+
+class Isotropic:
+	"""Batch filler with the reference's interface (src/primate/random.py:100-142): `values` is an (n, b)
+	Fortran-ordered array that every `fill()` redraws in place.
+
+	Host mode (default) keeps the reference's stream: one generator for `threads == 1`, otherwise `threads` child
+	generators spawned from the seed, child i filling the i-th block of ceil(b / threads) columns, concurrently.
+	`device=True` draws on the GPU instead (Philox stream of `slq_dmat_generate`, probe ids advancing by b per
+	fill): `device_values` is the resident `DeviceMatrix`, `values` downloads it."""
+
+	def __init__(self, size: tuple, pdf: str = "signs", seed: Union[int, np.random.SeedSequence, np.random.Generator, None] = None,
+	             threads: Optional[int] = None, device: bool = False):  # fmt: skip
+		assert pdf in _ISO_DISTRIBUTIONS, f"Invalid distribution '{pdf}' supplied."
+		self.pdf = _ISO_DISTRIBUTIONS[pdf]
+		self.shape = tuple(size)
+		self.threads = multiprocessing.cpu_count() if threads is None else int(threads)
+		self._device = bool(device)
+		if self._device:
+			from .engine import DeviceMatrix
+
+			self._seed = int(seed) if isinstance(seed, (int, np.integer)) else int(np.random.default_rng(seed).integers(0, 2**62))
+			self._drawn = 0
+			self.device_values = DeviceMatrix(self.shape[0], self.shape[1])
+			return
+		rng = np.random.default_rng(seed)
+		self._random_generators = [rng] if self.threads == 1 else rng.spawn(self.threads)
+		self.executor = concurrent.futures.ThreadPoolExecutor(self.threads)
+		self._values = np.zeros(self.shape, order="F")  # column blocks are contiguous: safe to fill concurrently
+		self.step = int(np.ceil(self.shape[1] / self.threads))
+
+	@property
+	def values(self) -> np.ndarray:
+		return self.device_values.get() if self._device else self._values
+
+	def fill(self) -> None:
+		if self._device:
+			self.device_values.generate(0, self.shape[1], self.pdf, seed=self._seed, probe_offset=self._drawn)
+			self._drawn += self.shape[1]
+			return
+		jobs = [
+			self.executor.submit(_fill, g, self.pdf, self._values[:, i * self.step : (i + 1) * self.step])
+			for i, g in enumerate(self._random_generators)
+			if i * self.step < self.shape[1]
+		]
+		concurrent.futures.wait(jobs)
+		for j in jobs:
+			j.result()
+
+	def __del__(self):
+		ex = getattr(self, "executor", None)
+		if ex is not None:
+			ex.shutdown(False)
+
+
+def symmetric(n: int, dist: str = "normal", pd: bool = False, ew: Optional[np.ndarray] = None, seed: Union[int, np.random.Generator, None] = None) -> np.ndarray:
+	"""Random symmetric n x n matrix with prescribed eigenvalues (src/primate/random.py:145-181; the operator of
+	BASELINE.json configs[0] and of the reference's tests). The eigenvectors are the Q factor of a random symmetric
+	matrix whose strict upper triangle is drawn first (`dist`), then its diagonal (uniform); the eigenvalues `ew`
+	default to uniform draws on [-1, 1], or [0, 1] with `pd`. The draw order is the reference's, so equal seeds give
+	equal matrices."""
+	rng = np.random.default_rng(seed)
+	if dist not in ("uniform", "normal"):
+		raise ValueError(f"Invalid distribution {dist} supplied")
+	off = rng.uniform(size=n * (n - 1) // 2) if dist == "uniform" else rng.normal(size=n * (n - 1) // 2)
+	B = np.zeros((n, n))
+	B[np.triu_indices(n, k=1)] = off  # row-major upper triangle: scipy's squareform layout
+	B += B.T
+	B[np.diag_indices(n)] = rng.random(n)
+	Q = np.linalg.qr(B)[0]
+	ew = rng.uniform(size=n, low=0.0 if pd else -1.0, high=1.0) if ew is None else np.atleast_1d(ew)
+	A = (Q * ew) @ Q.T
+	return (A + A.T) / 2
+
+
+def haar(n: int, ew: Optional[np.ndarray] = None, seed: Union[int, np.random.Generator, None] = None) -> np.ndarray:
+	"""U diag(ew) U^T with U drawn uniformly from the orthogonal group O(n) (src/primate/random.py:184-200);
+	`ew` defaults to uniform draws on [-1, 1], taken before U as in the reference."""
+	from scipy.stats import ortho_group
+
+	rng = np.random.default_rng(seed)
+	og = ortho_group(n, seed=rng)
+	ew = rng.uniform(size=n, low=-1.0, high=1.0) if ew is None else np.atleast_1d(ew)
+	assert len(ew) == n, "Number of eigenvalues must be <= `n`"
+	U = og.rvs()
+	return (U * ew) @ U.T

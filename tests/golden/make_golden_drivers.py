@@ -96,6 +96,40 @@ def main():
 	out["knee_samples"], out["knee_decisions"] = xs, np.array(dec)
 	prov["knee_*"] = "pure"
 
+	## helper modules the drivers lean on (pure reference): test-matrix generators, the threaded batch filler,
+	## confidence intervals, the tridiagonal eigensolver front end, the control-variate estimator
+	from primate.estimators import ControlVariableEstimator
+	from primate.random import Isotropic, haar, symmetric
+	from primate.stats import confidence_interval
+	from primate.tridiag import eigh_tridiag, eigvalsh_tridiag
+
+	out["sym_n12_s3"] = symmetric(12, seed=3)
+	out["sym_n9_uniform_pd_s9"] = symmetric(9, dist="uniform", pd=True, seed=9)
+	out["haar_n8_s4"] = haar(8, seed=4)
+	for th in (1, 3):
+		for pdf in ("signs", "sphere"):
+			iso = Isotropic((20, 5), pdf=pdf, seed=11, threads=th)
+			iso.fill()
+			iso.fill()
+			out[f"iso_{pdf}_t{th}"] = iso.values.copy()
+	xs_ci = np.random.default_rng(0).normal(size=30)
+	out["ci_samples"] = xs_ci
+	out["ci_t95"], out["ci_n90"] = np.array(confidence_interval(xs_ci)), np.array(confidence_interval(xs_ci, 0.9, "normal"))
+	rng_t = np.random.default_rng(5)
+	td, te = rng_t.uniform(1, 3, 24), np.r_[0.0, rng_t.uniform(0.2, 1.0, 23)]
+	tw, tZ = eigh_tridiag(td, te)
+	out["tri_d"], out["tri_e"], out["tri_w"], out["tri_absZ"] = td, te, tw, np.abs(tZ)
+	out["tri_w_only"] = eigvalsh_tridiag(td, te[1:])
+	rng_cv = np.random.default_rng(1235)
+	U = rng_cv.uniform(size=(250, 5)) * np.array([1, 2, 3, 1, 2])
+	y = np.min(np.c_[U[:, 0] + U[:, 3], U[:, 0] + U[:, 2] + U[:, 4], U[:, 1] + U[:, 2] + U[:, 3], U[:, 1] + U[:, 4]], axis=1)
+	ycv = np.minimum(U[:, 0] + U[:, 3], U[:, 1] + U[:, 4])
+	cve = ControlVariableEstimator(15 / 16)
+	cve.update(np.c_[y[:100], ycv[:100]])
+	cve.update(np.c_[y[100:], ycv[100:]])
+	out["cv_samples"], out["cv_estimate"], out["cv_alpha"] = np.c_[y, ycv], np.float64(cve.estimate), np.atleast_1d(cve.alpha)
+	prov["sym_*|haar_*|iso_*|ci_*|tri_*|cv_*"] = "pure"
+
 	out["provenance"] = np.array([f"{k}={v}" for k, v in sorted(prov.items())])
 	np.savez_compressed(HERE / "slq_golden_drivers.npz", **out)
 	print("wrote", HERE / "slq_golden_drivers.npz", (HERE / "slq_golden_drivers.npz").stat().st_size, "bytes")

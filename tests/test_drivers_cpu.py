@@ -73,3 +73,42 @@ def test_knee_criterion_and_update_trinv(gd):
 	for j in range(6):
 		Rinv = update_trinv(Rinv, R[: j + 1, j])
 	np.testing.assert_allclose(Rinv, np.linalg.inv(R), atol=1e-12)
+
+
+def test_helper_modules_match_reference_vectors(gd):
+	"""Host-side helpers that ship with the reference's driver modules (random.symmetric/haar/Isotropic,
+	stats.confidence_interval, estimators.ControlVariableEstimator, typing helpers) against vectors captured
+	from the reference itself (tests/golden/make_golden_drivers.py)."""
+	from primate_amd.estimators import ControlVariableEstimator, arr_summary
+	from primate_amd.random import Isotropic, haar, symmetric
+	from primate_amd.stats import Covariance, Mean, confidence_interval
+	from primate_amd.typing import restrict_kwargs, setdiff_kwargs
+
+	np.testing.assert_array_equal(symmetric(12, seed=3), gd["sym_n12_s3"])
+	np.testing.assert_array_equal(symmetric(9, dist="uniform", pd=True, seed=9), gd["sym_n9_uniform_pd_s9"])
+	assert np.all(np.linalg.eigvalsh(gd["sym_n9_uniform_pd_s9"]) > 0)
+	np.testing.assert_allclose(np.linalg.eigvalsh(symmetric(15, ew=np.linspace(1, 2, 15), seed=1)), np.linspace(1, 2, 15), rtol=1e-12)
+	np.testing.assert_array_equal(haar(8, seed=4), gd["haar_n8_s4"])
+	with pytest.raises(ValueError):
+		symmetric(5, dist="cauchy")
+	for th in (1, 3):
+		for pdf in ("signs", "sphere"):
+			iso = Isotropic((20, 5), pdf=pdf, seed=11, threads=th)
+			iso.fill()
+			iso.fill()
+			np.testing.assert_array_equal(iso.values, gd[f"iso_{pdf}_t{th}"])
+			assert iso.values.flags["F_CONTIGUOUS"]
+	np.testing.assert_allclose(confidence_interval(gd["ci_samples"]), gd["ci_t95"], rtol=1e-13)
+	np.testing.assert_allclose(confidence_interval(gd["ci_samples"], 0.9, "normal"), gd["ci_n90"], rtol=1e-13)
+	with pytest.raises(ValueError):
+		confidence_interval(gd["ci_samples"], sdist="cauchy")
+	cv = ControlVariableEstimator(15 / 16)
+	cv.update(gd["cv_samples"][:100])
+	cv.update(gd["cv_samples"][100:])
+	assert cv.estimate == pytest.approx(float(gd["cv_estimate"]), rel=1e-12) and len(cv) == 250
+	np.testing.assert_allclose(cv.alpha, gd["cv_alpha"], rtol=1e-10)
+	assert abs(cv.estimate - 1339 / 1440) < abs(gd["cv_samples"][:, 0].mean() - 1339 / 1440)  # the variance reduction at work
+	assert Mean is not None and Covariance is not None
+	f = lambda a, b=1: None  # noqa: E731
+	assert restrict_kwargs(f, {"a": 1, "c": 2}) == {"a": 1} and setdiff_kwargs(f, {"a": 1, "c": 2}) == {"c": 2}
+	assert arr_summary(None) == "None" and arr_summary(1.0) == "1.000"

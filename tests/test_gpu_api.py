@@ -3,12 +3,15 @@ the GPU: these read like the reference's own tests (tests/test_operator.py, test
 test_lanczos.py, test_quadrature.py in the reference tree) and also check golden driver outputs.
 """
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from conftest import laplacian_2d
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def spd(n, seed=1234, lo=None):
@@ -347,3 +350,45 @@ def test_hutchpp_device_path_matches_host_algebra(monkeypatch):
 		assert info.nit == 90 and info.samples.shape == (90,)
 		assert dev == pytest.approx(host, rel=1e-9), mode
 		assert abs(dev - exact) / exact < 2e-2
+
+
+def test_tridiag_fttr_and_isotropic_modules_on_device():
+	"""`primate.tridiag` / `primate.fttr` names and the device mode of `Isotropic`, against vectors captured from
+	the reference (LAPACK MRRR behind its eigh_tridiag) and against the plan generator."""
+	from primate_amd.engine import DeviceOperator, LanczosPlan
+	from primate_amd.fttr import fttr, ortho_poly
+	from primate_amd.random import Isotropic
+	from primate_amd.tridiag import eigh_tridiag, eigvalsh_tridiag
+
+	gd = np.load(ROOT / "tests" / "golden" / "slq_golden_drivers.npz")
+	d, e = gd["tri_d"], gd["tri_e"]
+	w, Z = eigh_tridiag(d, e)
+	np.testing.assert_allclose(w, gd["tri_w"], rtol=0, atol=2e-14)
+	np.testing.assert_allclose(np.abs(Z), gd["tri_absZ"], rtol=0, atol=1e-12)  # eigenvectors up to sign
+	T = np.diag(d) + np.diag(e[1:], 1) + np.diag(e[1:], -1)
+	np.testing.assert_allclose(T @ Z, Z * w, atol=1e-13)
+	np.testing.assert_allclose(Z.T @ Z, np.eye(len(d)), atol=1e-13)
+	np.testing.assert_allclose(eigvalsh_tridiag(d, e[1:]), gd["tri_w_only"], rtol=0, atol=2e-14)
+	with pytest.raises(AssertionError):
+		eigh_tridiag(d, e[:5])
+	## fttr with the reference's in-place signature, on the golden rule
+	wts = np.zeros(len(gd["fttr_nodes"]))
+	fttr(gd["fttr_nodes"], gd["fttr_alpha"], gd["fttr_beta"], len(wts), wts)
+	np.testing.assert_allclose(wts, gd["fttr_weights"], rtol=1e-10)
+	z = np.zeros(len(gd["fttr_alpha"]))
+	mu0 = np.sum(np.abs(gd["fttr_nodes"]))
+	ortho_poly(gd["fttr_nodes"][0], 1 / np.sqrt(mu0), gd["fttr_alpha"], gd["fttr_beta"], z, len(z))
+	assert 1.0 / (mu0 * np.sum(z * z)) == pytest.approx(gd["fttr_weights"][0], rel=1e-10)
+	## Isotropic(device=True): same stream as the plan generator, ids advancing with every fill
+	L = laplacian_2d(12)
+	n = L.shape[0]
+	plan = LanczosPlan(DeviceOperator(L), 6, 5, 0)
+	for pdf in ("signs", "normal", "sphere"):
+		iso = Isotropic((n, 6), pdf=pdf, seed=21, device=True)
+		for rep in range(2):
+			iso.fill()
+			plan.generate_probes({"signs": "rademacher"}.get(pdf, pdf), seed=21, probe_offset=6 * rep)
+			X = plan.get_probes()
+			if pdf == "sphere":
+				X = X * (np.sqrt(n) / np.linalg.norm(X, axis=0))
+			np.testing.assert_allclose(iso.values, X, rtol=1e-13)
