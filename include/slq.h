@@ -170,7 +170,7 @@ int slq_quadrature_batch(slq_context *ctx, int nb, int deg, const double *d, con
 /* Full eigendecomposition of nb symmetric tridiagonals (eigh_tridiag / eigvalsh_tridiag,
  * src/primate/tridiag.py:25-62; what rayleigh_ritz and MatrixFunction._matvec call): d, e as above
  * (e[:,0] ignored). w: nb x deg ascending eigenvalues. Z: nb x deg x deg row-major, eigenvectors in the
- * COLUMNS of each matrix, or NULL for eigenvalues only. deg <= 141 (eigenvectors live in LDS). */
+ * COLUMNS of each matrix, or NULL for eigenvalues only. deg <= 512 (eigenvectors on chip up to 141). */
 int slq_eigh_tridiag_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e, double *w, double *Z);
 
 /* Tall-skinny dense algebra for the exchangeable estimators (xtrace / hutch++: the host-side

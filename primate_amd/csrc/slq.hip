@@ -1498,16 +1498,26 @@ static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) 
   hipStream_t st = p->ctx->stream;
   const int deg = p->deg;
   const double p0 = fun_params ? fun_params[0] : 0.0, p1 = fun_params ? fun_params[1] : 0.0;
-  const size_t lds = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8;
-  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip eigenvector solve", deg);
+  // eigenvectors of every probe's T: in LDS up to deg = 141, beyond that in a global scratch (stays in L2)
+  const size_t lds_onchip = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8;
+  const bool zg = lds_onchip > 160 * 1024;
+  const size_t lds = zg ? (size_t)2 * deg * 8 : lds_onchip;
+  double *zscr = nullptr;
+  if (zg) HIP_TRY(hipMalloc((void **)&zscr, (size_t)p->nprobes * deg * (deg + 1) * 8));
+  struct ScratchGuard { double *q; ~ScratchGuard() { if (q) hipFree(q); } } guard{zscr};
   if (lds > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fun_coeffs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fun_coeffs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipMemsetAsync(p->fail_d, 0, sizeof(int), st));
   // gamma row deg-1-t = -g_t: the update kernel's "w -= gamma W" then accumulates +g_t W_t into a
   // zeroed slot while walking t = deg-1 .. 0
   HIP_TRY(hipMemsetAsync(p->st.gamma, 0, (size_t)deg * p->bpad * 8, st));
-  PROFILED(p, SLQ_K_QUADRATURE,
-           (k_fun_coeffs<<<dim3(p->nprobes), dim3(64), lds, st>>>(p->st, fun_id, p0, p1, -1.0, 1, p->st.gamma, p->fail_d)));
+  if (zg) {
+    PROFILED(p, SLQ_K_QUADRATURE,
+             (k_fun_coeffs<true><<<dim3(p->nprobes), dim3(64), lds, st>>>(p->st, fun_id, p0, p1, -1.0, 1, p->st.gamma, zscr, p->fail_d)));
+  } else {
+    PROFILED(p, SLQ_K_QUADRATURE,
+             (k_fun_coeffs<false><<<dim3(p->nprobes), dim3(64), lds, st>>>(p->st, fun_id, p0, p1, -1.0, 1, p->st.gamma, nullptr, p->fail_d)));
+  }
   // output accumulates in slot `deg` (the spare slot behind the basis; it held the last residual)
   HIP_TRY(hipMemsetAsync(slot_ptr(p, deg), 0, (size_t)p->slot_stride * p->esz, st));
   SLQ_TRY(launch_reorth_update(p, deg - 1, deg, 0));
@@ -1853,23 +1863,28 @@ extern "C" int slq_fttr_batch(slq_context *ctx, int nb, int n, int k, const doub
 extern "C" int slq_eigh_tridiag_batch(slq_context *ctx, int nb, int deg, const double *d, const double *e, double *w,
                                       double *Z) {
   if (!ctx || !d || !e || !w) return fail(SLQ_EINVAL, "ctx/d/e/w is NULL");
-  if (nb <= 0 || deg <= 0) return fail(SLQ_EINVAL, "bad batch size or degree");
-  const size_t lds = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8 + (size_t)deg * sizeof(int);
-  if (lds > 160 * 1024) return fail(SLQ_EINVAL, "deg %d too large for the on-chip eigenvector solve", deg);
+  if (nb <= 0 || deg <= 0 || deg > kMaxDeg) return fail(SLQ_EINVAL, "bad batch size or degree (deg <= %d)", kMaxDeg);
+  // eigenvectors on chip when they fit in LDS (deg <= 141), otherwise in a global scratch that stays in L2
+  const size_t lds_onchip = ((size_t)2 * deg + (size_t)deg * (deg + 1)) * 8 + (size_t)deg * sizeof(int);
+  const bool zg = lds_onchip > 160 * 1024;
+  const size_t lds = zg ? (size_t)2 * deg * 8 + (size_t)deg * sizeof(int) : lds_onchip;
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const size_t in = (size_t)nb * deg, zz = Z ? in * deg : 0;
+  const size_t in = (size_t)nb * deg, zz = Z ? in * deg : 0, zs = zg ? in * (deg + 1) : 0;
   double *buf = nullptr;
-  HIP_TRY(hipMalloc((void **)&buf, (3 * in + zz + 1) * 8));
-  double *dd = buf, *de = dd + in, *dw = de + in, *dz = Z ? dw + in : nullptr;
-  int *dfail = (int *)(dw + in + zz);
+  HIP_TRY(hipMalloc((void **)&buf, (3 * in + zz + zs + 1) * 8));
+  double *dd = buf, *de = dd + in, *dw = de + in, *dz = Z ? dw + in : nullptr, *dscr = zg ? dw + in + zz : nullptr;
+  int *dfail = (int *)(dw + in + zz + zs);
   hipError_t err = hipMemcpyAsync(dd, d, in * 8, hipMemcpyHostToDevice, st);
   if (err == hipSuccess) err = hipMemcpyAsync(de, e, in * 8, hipMemcpyHostToDevice, st);
   if (err == hipSuccess) err = hipMemsetAsync(dfail, 0, sizeof(int), st);
   if (err == hipSuccess && lds > 48 * 1024)
-    err = hipFuncSetAttribute((const void *)k_eigh_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    err = hipFuncSetAttribute((const void *)k_eigh_tridiag<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (err == hipSuccess) {
-    k_eigh_tridiag<<<dim3(nb), dim3(64), lds, st>>>(deg, dd, de, dw, dz, dfail);
+    if (zg)
+      k_eigh_tridiag<true><<<dim3(nb), dim3(64), lds, st>>>(deg, dd, de, dw, dz, dscr, dfail);
+    else
+      k_eigh_tridiag<false><<<dim3(nb), dim3(64), lds, st>>>(deg, dd, de, dw, dz, nullptr, dfail);
     err = hipGetLastError();
   }
   int bad = 0;

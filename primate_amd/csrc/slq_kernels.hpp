@@ -285,13 +285,13 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       } else {
         w -= cb * xc;
         if (PASS == PASS_DOTS) {
-          if (RC > 0) dacc[0] += xc * w;
-          if (RC > 1) dacc[1] += xp * w;
+          if constexpr (RC > 0) dacc[0] += xc * w;
+          if constexpr (RC > 1) dacc[1] += xp * w;
 #pragma unroll
           for (int i = 2; i < RC; ++i) dacc[i] += u[i - 2] * w;
         } else {
-          if (RC > 0) w -= gm[0] * xc;
-          if (RC > 1) w -= gm[1] * xp;
+          if constexpr (RC > 0) w -= gm[0] * xc;
+          if constexpr (RC > 1) w -= gm[1] * xp;
 #pragma unroll
           for (int i = 2; i < RC; ++i) w -= gm[i] * u[i - 2];
           stream_store<NTP>((VF *)(wn + ro), w);
@@ -1341,23 +1341,27 @@ __device__ __forceinline__ int ql_implicit_full(double *d, double *e, double *Z,
 // d/e are the same from every lane); the plane rotations are applied lane-parallel, lane r owning
 // rows r, r+64, ... of Y. coef[t][col] = sign * g_t (0 where nu_t = 0, i.e. past an early stop);
 // reverse_rows stores g_t in row k-1-t, the order in which k_reorth_update walks the ring.
+// ZG: the k x k eigenvector matrix lives in LDS (false, k <= 141) or in a per-probe global scratch (true).
+template <bool ZG>
 __global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, double p0, double p1,
                                                    double sign, int reverse_rows,
-                                                   double *__restrict__ coef,
+                                                   double *__restrict__ coef, double *zscratch,
                                                    int *__restrict__ fail) {
   extern __shared__ double lds[];
   const int k = st.deg, ldz = k + 1;
-  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
   const int lane = threadIdx.x, col = blockIdx.x;
+  double *d = lds, *e = lds + k;
+  double *Z = ZG ? zscratch + (int64_t)col * k * ldz : lds + 2 * k;
   for (int i = lane; i < k; i += 64) {
     d[i] = st.alpha[(int64_t)i * st.bpad + col];
     e[i] = (i + 1 < k) ? st.nu[(int64_t)(i + 1) * st.bpad + col] : 0.0;
   }
-  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
-  __syncthreads();
-  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
+  for (int row = lane; row < k; row += 64)  // a lane initialises (and later rotates) the rows it owns
+    for (int c = 0; c < k; ++c) Z[row * ldz + c] = (c == row) ? 1.0 : 0.0;
+  __threadfence_block();
   __syncthreads();
   const int bad = ql_implicit_full(d, e, Z, k, ldz, lane);
+  __threadfence_block();
   __syncthreads();
   // e[i] <- f(theta_i) * Y[0,i]
   for (int i = lane; i < k; i += 64) e[i] = apply_fun(fun_id, p0, p1, d[i]) * Z[i];
@@ -1377,23 +1381,29 @@ __global__ __launch_bounds__(64) void k_fun_coeffs(StepState st, int fun_id, dou
 // reference: eigh_tridiag, src/primate/tridiag.py:25-44). One wave per matrix; din/ein are nb x k row-major with
 // ein[:, i] coupling i-1 and i (ein[:, 0] ignored); eigenvalues ascending into w (nb x k), eigenvectors as the
 // COLUMNS of Zout (nb x k x k, row-major per matrix) when Zout != null.
+template <bool ZG>
 __global__ __launch_bounds__(64) void k_eigh_tridiag(int k, const double *__restrict__ din, const double *__restrict__ ein,
-                                                     double *__restrict__ w, double *__restrict__ Zout, int *__restrict__ fail) {
+                                                     double *__restrict__ w, double *__restrict__ Zout, double *zscratch,
+                                                     int *__restrict__ fail) {
+  // ZG = false: the k x k eigenvector matrix lives in LDS (k <= 141); ZG = true: in a per-matrix global scratch
+  // (k x (k+1) doubles, L2-resident), for larger k. Each lane only ever touches its own rows of Z until the end.
   extern __shared__ double lds[];
   const int ldz = k + 1;
-  double *d = lds, *e = lds + k, *Z = lds + 2 * k;
-  int *ord = (int *)(Z + (size_t)k * ldz);
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
+  double *d = lds, *e = lds + k;
+  double *Z = ZG ? zscratch + b * (int64_t)k * ldz : lds + 2 * k;
+  int *ord = (int *)(ZG ? lds + 2 * k : lds + 2 * k + (size_t)k * ldz);
   for (int i = lane; i < k; i += 64) {
     d[i] = din[b * k + i];
     e[i] = (i + 1 < k) ? ein[b * k + i + 1] : 0.0;
   }
-  for (int idx = lane; idx < k * ldz; idx += 64) Z[idx] = 0.0;
-  __syncthreads();
-  for (int i = lane; i < k; i += 64) Z[i * ldz + i] = 1.0;
+  for (int row = lane; row < k; row += 64)
+    for (int c = 0; c < k; ++c) Z[row * ldz + c] = (c == row) ? 1.0 : 0.0;
+  __threadfence_block();
   __syncthreads();
   const int bad = ql_implicit_full(d, e, Z, k, ldz, lane);
+  __threadfence_block();
   __syncthreads();
   // ascending order by rank counting (ties broken by index): ord[rank] = source column
   for (int i = lane; i < k; i += 64) {
@@ -1405,10 +1415,8 @@ __global__ __launch_bounds__(64) void k_eigh_tridiag(int k, const double *__rest
   __syncthreads();
   for (int i = lane; i < k; i += 64) w[b * k + i] = d[ord[i]];
   if (Zout)
-    for (int idx = lane; idx < k * k; idx += 64) {
-      const int row = idx / k, col = idx % k;
-      Zout[b * k * k + idx] = Z[row * ldz + ord[col]];
-    }
+    for (int row = lane; row < k; row += 64)  // a lane writes out the rows it owns
+      for (int col = 0; col < k; ++col) Zout[b * k * k + (int64_t)row * k + col] = Z[row * ldz + ord[col]];
   if (bad && lane == 0) atomicOr(fail, 1);
 }
 

@@ -148,6 +148,23 @@ class ConvergenceCriterion:
 		return "Composite convergence criterion"
 
 
+class Estimator:
+	"""Interface of an updateable estimator (src/primate/estimators.py:35-53): a length (samples seen), an
+	`update(x)` and an `estimate`; `values` optionally records the samples, `delta` is the last change."""
+
+	n_samples: int = 0
+	values = None
+	delta = np.inf
+
+	def __len__(self) -> int:
+		return self.n_samples
+
+	def update(self, x): ...
+
+	@property
+	def estimate(self): ...
+
+
 class ControlVariableEstimator(MeanEstimator):
 	"""Mean of a scalar response corrected by control variates with known expectations `ecv`
 	(src/primate/estimators.py:148-196): samples are rows [y, c_1, ..., c_m]; the estimate is

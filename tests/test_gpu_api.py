@@ -371,6 +371,27 @@ def test_tridiag_fttr_and_isotropic_modules_on_device():
 	np.testing.assert_allclose(eigvalsh_tridiag(d, e[1:]), gd["tri_w_only"], rtol=0, atol=2e-14)
 	with pytest.raises(AssertionError):
 		eigh_tridiag(d, e[:5])
+	## the reference's own test (tests/test_tridiagonal.py:11-44): d = 150 needs the global-scratch variant
+	from primate_amd.lanczos import lanczos
+	from primate_amd.random import symmetric
+	from primate_amd.tqli import tqli
+
+	for seed in [1234, 43]:
+		rng = np.random.default_rng(seed)
+		k = 150
+		ew = np.sort(rng.uniform(size=k, low=1 / k, high=1))
+		A = symmetric(k, seed=rng, pd=True, ew=ew)
+		a, b = lanczos(A, v0=rng.uniform(size=k), deg=k, orth=k)
+		for method in ["tqli", "mrrr"]:
+			assert np.max(np.abs(np.sort(eigvalsh_tridiag(a, b, method=method)) - ew)) <= 1e-13
+			ew_t, ev_t = eigh_tridiag(a, b, method=method)
+			np.testing.assert_allclose(ev_t.T @ ev_t, np.eye(k), atol=1e-12)
+			np.testing.assert_allclose(np.sort(ew_t), ew, atol=1e-13)
+		dd, ee, Zt = a.copy(), np.append([0], b), np.eye(k)
+		tqli(dd, ee, Zt, 30)
+		assert np.allclose(np.sort(dd), ew) and np.allclose(ee, 0.0)
+		Tm = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+		np.testing.assert_allclose(Tm @ Zt, Zt * dd, atol=1e-12)
 	## fttr with the reference's in-place signature, on the golden rule
 	wts = np.zeros(len(gd["fttr_nodes"]))
 	fttr(gd["fttr_nodes"], gd["fttr_alpha"], gd["fttr_beta"], len(wts), wts)

@@ -285,6 +285,12 @@ def test_one_call_fun_action_batch(eng, golden):
 	np.testing.assert_allclose(eng.fun_action_batch(op, X, deg=25, orth=5, fun="exp", t=-0.2), plan.fun_action("exp", t=-0.2), rtol=1e-12, atol=1e-13)
 	with pytest.raises(ValueError):
 		eng.fun_action_batch(op, X[:5], deg=10)
+	## deg > 141: the eigenvector matrices no longer fit in LDS and live in a global scratch
+	A2 = random_spd_graph(400, 6.0, seed=8)
+	w2, U2 = np.linalg.eigh(A2.toarray())
+	X2 = np.asfortranarray(rng.standard_normal((400, 5)))
+	Y2 = eng.fun_action_batch(eng.DeviceOperator(A2), X2, deg=200, orth=200, fun="exp", t=-0.3)
+	np.testing.assert_allclose(Y2, (U2 * np.exp(-0.3 * w2)) @ (U2.T @ X2), rtol=1e-8, atol=1e-9)
 
 
 def test_standalone_quadrature_entry(eng, golden, oracle):
