@@ -88,6 +88,12 @@ class Isotropic:
 		self.executor = concurrent.futures.ThreadPoolExecutor(self.threads)
 		self._values = np.zeros(self.shape, order="F")  # column blocks are contiguous: safe to fill concurrently
 		self.step = int(np.ceil(self.shape[1] / self.threads))
+		## (generator, column block) pairs, fixed for the life of the filler
+		self._blocks = [
+			(g, self._values[:, i * self.step : (i + 1) * self.step])
+			for i, g in enumerate(self._random_generators)
+			if i * self.step < self.shape[1]
+		]
 
 	@property
 	def values(self) -> np.ndarray:
@@ -98,12 +104,10 @@ class Isotropic:
 			self.device_values.generate(0, self.shape[1], self.pdf, seed=self._seed, probe_offset=self._drawn)
 			self._drawn += self.shape[1]
 			return
-		jobs = [
-			self.executor.submit(_fill, g, self.pdf, self._values[:, i * self.step : (i + 1) * self.step])
-			for i, g in enumerate(self._random_generators)
-			if i * self.step < self.shape[1]
-		]
-		concurrent.futures.wait(jobs)
+		if len(self._blocks) == 1:
+			_fill(self._blocks[0][0], self.pdf, self._blocks[0][1])
+			return
+		jobs = [self.executor.submit(_fill, g, self.pdf, view) for g, view in self._blocks]
 		for j in jobs:
 			j.result()
 
