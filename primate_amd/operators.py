@@ -193,3 +193,26 @@ def matrix_function(A, fun: Optional[Callable] = None, v: Optional[np.ndarray] =
 	"""operators.py:155-161."""
 	M = MatrixFunction(A, fun=fun, deg=deg)
 	return M if v is None else M._matvec(v)
+
+
+class Toeplitz(LinearOperator):
+	"""Matrix-free symmetric-or-not Toeplitz operator with first column `c` and first row `r` (default r = c),
+	applied by circulant embedding and two FFTs of length 2n (src/primate/operators.py:165-183). A host-side
+	plugin: `lanczos`/`MatrixFunction` reach it through the callback operator (`slq_callback_create`)."""
+
+	def __init__(self, c: np.ndarray, r: Optional[np.ndarray] = None, dtype: np.dtype = np.float64):
+		self.c = np.array(c)
+		self.r = np.array(c if r is None else r)
+		n = len(self.c)
+		## first column of the 2n x 2n circulant that contains T in its leading block: [c, 0, r_{n-1}, ..., r_1]
+		self._symbol = np.fft.fft(np.concatenate((self.c, [0], self.r[:0:-1])))
+		self._pad = np.zeros(2 * n)
+		self.shape = (n, n)
+		self.dtype = np.dtype(dtype)
+
+	def _matvec(self, x: np.ndarray) -> np.ndarray:
+		n = self.shape[0]
+		assert np.size(x) == n, f"Invalid shape of input vector 'x'; must have length {n}"
+		self._pad[:n] = np.ravel(x)
+		y = np.fft.ifft(self._symbol * np.fft.fft(self._pad))
+		return np.real(y[:n]).astype(self.dtype)

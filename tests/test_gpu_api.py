@@ -413,3 +413,23 @@ def test_tridiag_fttr_and_isotropic_modules_on_device():
 			if pdf == "sphere":
 				X = X * (np.sqrt(n) / np.linalg.norm(X, axis=0))
 			np.testing.assert_allclose(iso.values, X, rtol=1e-13)
+
+
+def test_toeplitz_plugin_through_the_callback_operator():
+	"""A matrix-free host plugin (FFT-applied Toeplitz) driven by the device Lanczos through the callback operator:
+	same tridiagonal and quadrature as the dense matrix it represents."""
+	from scipy.linalg import toeplitz
+
+	from primate_amd.lanczos import lanczos
+	from primate_amd.operators import MatrixFunction, Toeplitz
+
+	n = 64
+	c = 0.5 ** np.arange(n)  # Kac-Murdock-Szego matrix: SPD
+	T, Td = Toeplitz(c), toeplitz(c)
+	v = np.random.default_rng(0).standard_normal(n)
+	(a1, b1), (a2, b2) = lanczos(T, v0=v, deg=20, orth=5), lanczos(Td, v0=v, deg=20, orth=5)
+	np.testing.assert_allclose(a1, a2, rtol=1e-9, atol=1e-11)
+	np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-11)
+	M1, M2 = MatrixFunction(T, fun="log", deg=20), MatrixFunction(Td, fun="log", deg=20)
+	X = np.random.default_rng(1).standard_normal((n, 6))
+	np.testing.assert_allclose(M1.quad(X), M2.quad(X), rtol=1e-9)

@@ -201,3 +201,18 @@ def test_sharded_reduce_world2_gloo(tmp_path):
 	outs = [p.communicate(timeout=300)[0].decode() for p in procs]
 	assert all(p.returncode == 0 for p in procs), outs
 	assert all("OK" in o for o in outs), outs
+
+
+def test_toeplitz_plugin_operator_on_the_host():
+	"""The FFT-applied Toeplitz plugin equals the dense Toeplitz product (symmetric and non-symmetric)."""
+	from scipy.linalg import toeplitz
+
+	from primate_amd.operators import Toeplitz, is_linear_op, is_valid_operator
+
+	rng = np.random.default_rng(3)
+	c, r = rng.standard_normal(17), rng.standard_normal(17)
+	r[0] = c[0]
+	x = rng.standard_normal(17)
+	np.testing.assert_allclose(Toeplitz(c) @ x, toeplitz(c) @ x, rtol=1e-12, atol=1e-12)
+	np.testing.assert_allclose(Toeplitz(c, r) @ x, toeplitz(c, r) @ x, rtol=1e-12, atol=1e-12)
+	assert is_linear_op(Toeplitz(c)) and is_valid_operator(Toeplitz(c)) == np.float64
