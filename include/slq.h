@@ -82,6 +82,10 @@ typedef struct slq_dmat slq_dmat;         /* column-major n x m fp64 matrix resi
  * LinearOperators; mirrors PyLinearOperator::matvec, src/primate/include/pylinop.h:32-40).
  * x has ncols entries, y nrows entries, both of the operator's dtype. Return 0 on success. */
 typedef int (*slq_matvec_fn)(void *user, const void *x, void *y);
+/* Device plugin: Y = A X for ncols columns; d_X, d_Y are DEVICE pointers to column-major n x ncols arrays of
+ * the operator dtype (leading dimension n). The callee enqueues its work on `stream` (a hipStream_t), or on
+ * any stream provided it has completed or been ordered after/before `stream` when it returns. Nonzero = error. */
+typedef int (*slq_matmat_device_fn)(void *user, const void *d_X, void *d_Y, int64_t n, int ncols, void *stream);
 
 /* ---- context -------------------------------------------------------------------------------- */
 const char *slq_last_error(void);
@@ -108,6 +112,11 @@ int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
 int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const void *A, int64_t lda,
                      slq_operator **out);
 /* Host-callback operator (device <-> host round trip per Lanczos step and probe). */
+/* A GPU-resident LinearOperator plugin (e.g. a torch module, a user's HIP kernel): the Lanczos vectors never
+ * leave HBM. Same place in the reference: any object satisfying the LinearOperator concept
+ * (src/primate/include/linear_operator.h:25-29), here with device buffers. */
+int slq_device_callback_create(slq_context *ctx, int dtype, int64_t n, slq_matmat_device_fn fn, void *user,
+                               slq_operator **out);
 int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_matvec_fn fn, void *user,
                         slq_operator **out);
 int slq_operator_destroy(slq_operator *op);

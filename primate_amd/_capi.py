@@ -79,6 +79,7 @@ _SIGNATURES = {
 	"slq_dmat_gemm_nn": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, C.c_double, C.c_double]),
 	"slq_plan_fun_action_dmat": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
 	"slq_plan_get_probes_dmat": (C.c_int, [_P, _P, C.c_int]),
+	"slq_device_callback_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P]),
 	"slq_dmat_generate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64]),
 	"slq_dmat_copy": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
 	"slq_measure_stream": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
@@ -96,6 +97,7 @@ _SIGNATURES = {
 	"slq_lanczos_f64": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, _P, C.c_size_t]),
 	"slq_lanczos_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_size_t]),
 }  # fmt: skip
+DEVICE_MATMAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 

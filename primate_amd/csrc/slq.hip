@@ -60,7 +60,7 @@ struct slq_context {
   int num_cus;
 };
 
-enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2 };
+enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2, OP_DEVICE_CALLBACK = 3 };
 
 struct slq_operator {
   slq_context *ctx;
@@ -79,6 +79,7 @@ struct slq_operator {
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
   void *vals_u = nullptr;
+  slq_matmat_device_fn dev_fn = nullptr;  // OP_DEVICE_CALLBACK: Y = A X on device buffers, enqueued on our stream
   double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
   int64_t nnz_u = 0;       // entries of the upper-triangle copy
   double far_per_row = 0.0;  // stored nonzeros per row with |i - j| > 4096 (0 when unknown: device-resident CSR)
@@ -613,6 +614,20 @@ extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_m
   return SLQ_OK;
 }
 
+extern "C" int slq_device_callback_create(slq_context *ctx, int dtype, int64_t n, slq_matmat_device_fn fn, void *user,
+                                          slq_operator **out) {
+  if (!ctx || !out || !fn) return fail(SLQ_EINVAL, "ctx/out/fn is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || n >= (int64_t)1 << 31) return fail(SLQ_EINVAL, "bad operator size");
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  *op = slq_operator{ctx, OP_DEVICE_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, nullptr, user, nullptr, nullptr, RowTiles{}};
+  op->dev_fn = fn;
+  *out = op;
+  return SLQ_OK;
+}
+
 extern "C" int slq_operator_destroy(slq_operator *op) {
   if (!op) return SLQ_OK;
   if (op->owns) {
@@ -1129,6 +1144,30 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
                                           (const F *)op->vals, op->lda, (const F *)slot_ptr(p, slot_c), (F *)p->T))));
     return SLQ_OK;
   }
+  if (op->kind == OP_DEVICE_CALLBACK) {
+    // device plugin: the panel goes through two column-major staging buffers in HBM (X | Y); the plugin
+    // enqueues Y = A X on our stream (or synchronises itself) - nothing crosses PCIe
+    const int cc = std::max(1, stage_chunk_cols(p) / 2);
+    SLQ_TRY(ensure_stage(p, 2 * cc));
+    char *sx = (char *)p->stage, *sy = sx + (size_t)cc * p->n * p->esz;
+    HIP_TRY(hipMemsetAsync(p->T, 0, (size_t)p->slot_stride * p->esz, st));
+    for (int c0 = 0; c0 < p->nprobes; c0 += cc) {
+      const int nc = std::min(cc, p->nprobes - c0);
+      dim3 g((p->n + 63) / 64, (nc + 63) / 64);
+      if (p->dtype == SLQ_F64)
+        hipLaunchKernelGGL(k_panel_to_cols<double>, g, dim3(256), 0, st, p->n, (const double *)slot_ptr(p, slot_c), c0, nc, (double *)sx, p->PW, (const double *)nullptr, (const int32_t *)nullptr);
+      else
+        hipLaunchKernelGGL(k_panel_to_cols<float>, g, dim3(256), 0, st, p->n, (const float *)slot_ptr(p, slot_c), c0, nc, (float *)sx, p->PW, (const double *)nullptr, (const int32_t *)nullptr);
+      if (op->dev_fn(op->user, sx, sy, p->n, nc, (void *)st) != 0)
+        return fail(SLQ_ECALLBACK, "device operator callback failed on columns %d..%d", c0, c0 + nc - 1);
+      if (p->dtype == SLQ_F64)
+        hipLaunchKernelGGL(k_cols_to_panel<double>, g, dim3(256), 0, st, p->n, (const double *)sy, c0, nc, (double *)p->T, p->PW, (const int32_t *)nullptr);
+      else
+        hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)sy, c0, nc, (float *)p->T, p->PW, (const int32_t *)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+    return SLQ_OK;
+  }
   // host callback: device -> host, one matvec per probe, host -> device
   const size_t colb = (size_t)p->n * p->esz;
   if (p->hbuf.size() < 2 * colb * (size_t)p->nprobes) p->hbuf.resize(2 * colb * (size_t)p->nprobes);
@@ -1347,7 +1386,7 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   // the plan, so it is captured into a hipGraph once and replayed: launch-bound for small n,
   // a few per cent for n = 1e6. Not used while per-kernel events are recorded, nor for host-callback
   // operators (they synchronise with the host every step).
-  const bool graph_ok = env_int("SLQ_GRAPH", 1) != 0 && !p->prof && p->op->kind != OP_CALLBACK;
+  const bool graph_ok = env_int("SLQ_GRAPH", 1) != 0 && !p->prof && p->op->kind != OP_CALLBACK && p->op->kind != OP_DEVICE_CALLBACK;
   if (!graph_ok) {
     SLQ_TRY(enqueue_run(p, rtol, fused, nt));
   } else {

@@ -122,6 +122,24 @@ class DeviceOperator:
 			vals = np.ascontiguousarray(M.data, dtype=self.dtype)
 			check(L.slq_csr_create(self.ctx._h, dt, M.shape[0], M.nnz, ptr(rowptr), ptr(colind), ptr(vals), C.byref(h)))
 			self.kind, self.nnz = "csr", int(M.nnz)
+		elif hasattr(A, "matmat_device"):
+			## GPU-resident plugin: A.matmat_device(X, Y, stream) receives two objects with
+			## `__cuda_array_interface__` (shape (ncols, n), C order = column-major n x ncols) and a stream handle
+			n, np_dt = self.shape[0], self.dtype
+			self.error = None
+
+			def _dcb(_user, dx, dy, nn, ncols, stream):
+				try:
+					A.matmat_device(_CudaArrayView(dx, nn * ncols, self, (ncols, nn), np_dt), _CudaArrayView(dy, nn * ncols, self, (ncols, nn), np_dt), stream)
+					return 0
+				except Exception as e:  # noqa: BLE001
+					self.error = e
+					return 1
+
+			dcb = _capi.DEVICE_MATMAT_FN(_dcb)
+			self._keep.append(dcb)
+			check(L.slq_device_callback_create(self.ctx._h, dt, n, dcb, None, C.byref(h)))
+			self.kind, self.nnz = "device_callback", 0
 		else:
 			if not hasattr(A, "matvec"):
 				raise ValueError("Supplied object is missing 'matvec' attribute.")
@@ -413,9 +431,12 @@ class DiagAccumulator:
 class _CudaArrayView:
 	"""Flat fp64 device array described by the CUDA array interface (v2); keeps its owner alive."""
 
-	def __init__(self, dptr: int, count: int, owner):
+	def __init__(self, dptr: int, count: int, owner, shape=None, dtype=np.float64):
 		self._owner = owner
-		self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(dptr), False), "version": 2}
+		self.__cuda_array_interface__ = {
+			"shape": tuple(int(v) for v in shape) if shape is not None else (int(count),),
+			"typestr": "<f8" if np.dtype(dtype) == np.float64 else "<f4", "data": (int(dptr), False), "version": 2,
+		}  # fmt: skip
 
 
 class DeviceMatrix:

@@ -216,3 +216,30 @@ class Toeplitz(LinearOperator):
 		self._pad[:n] = np.ravel(x)
 		y = np.fft.ifft(self._symbol * np.fft.fft(self._pad))
 		return np.real(y[:n]).astype(self.dtype)
+
+
+class TorchOperator(LinearOperator):
+	"""A symmetric operator given as a function on GPU-resident torch tensors, `fn(X) -> A X` for X of shape
+	(n, b) on this process's GPU. Used as `A` in `lanczos` / `MatrixFunction` / `hutch`, its products run inside
+	the device Lanczos loop on libslq's stream without a host round trip (`slq_device_callback_create`): the
+	GPU-native form of the reference's `LinearOperator` plugin surface (src/primate/operators.py:15-33)."""
+
+	def __init__(self, fn: Callable, n: int, dtype=np.float64):
+		self.fn, self.shape, self.dtype = fn, (int(n), int(n)), np.dtype(dtype)
+
+	def matmat_device(self, X, Y, stream) -> None:
+		import torch
+
+		dev = torch.device("cuda", torch.cuda.current_device())
+		with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+			x, y = torch.as_tensor(X, device=dev), torch.as_tensor(Y, device=dev)  # (b, n) views of column-major n x b
+			y.copy_(self.fn(x.T).T)
+
+	def _matmat(self, X: np.ndarray) -> np.ndarray:
+		import torch
+
+		dev = torch.device("cuda", torch.cuda.current_device())
+		return self.fn(torch.as_tensor(np.ascontiguousarray(X), device=dev).to(torch.float64 if self.dtype == np.float64 else torch.float32)).cpu().numpy()
+
+	def _matvec(self, x: np.ndarray) -> np.ndarray:
+		return self._matmat(np.asarray(x).reshape(-1, 1)).ravel()

@@ -433,3 +433,35 @@ def test_toeplitz_plugin_through_the_callback_operator():
 	M1, M2 = MatrixFunction(T, fun="log", deg=20), MatrixFunction(Td, fun="log", deg=20)
 	X = np.random.default_rng(1).standard_normal((n, 6))
 	np.testing.assert_allclose(M1.quad(X), M2.quad(X), rtol=1e-9)
+
+
+def test_torch_plugin_operator_stays_on_the_device():
+	"""A LinearOperator plugin written in torch (GPU tensors in, GPU tensors out) inside the device Lanczos loop:
+	same tridiagonal, quadrature and f(A)v as the dense matrix it wraps; errors raised in the plugin surface."""
+	import torch
+
+	from primate_amd.engine import DeviceOperator, quad_batch
+	from primate_amd.lanczos import lanczos
+	from primate_amd.operators import MatrixFunction, TorchOperator
+
+	A, _ = spd(300, seed=5)
+	At = torch.tensor(A, device="cuda")
+	T = TorchOperator(lambda X: At @ X, 300)
+	v = np.random.default_rng(0).standard_normal(300)
+	(a1, b1), (a2, b2) = lanczos(T, v0=v, deg=25, orth=25), lanczos(A, v0=v, deg=25, orth=25)
+	np.testing.assert_allclose(a1, a2, rtol=1e-9, atol=1e-12)
+	np.testing.assert_allclose(b1, b2, rtol=1e-9, atol=1e-12)
+	X = np.asfortranarray(np.random.default_rng(1).standard_normal((300, 70)))
+	op_t, op_d = DeviceOperator(T), DeviceOperator(A)
+	assert op_t.kind == "device_callback"
+	np.testing.assert_allclose(quad_batch(op_t, X, 20, 3, fun="log"), quad_batch(op_d, X, 20, 3, fun="log"), rtol=1e-10)
+	np.testing.assert_allclose(op_t.matmat(X), A @ X, rtol=1e-12, atol=1e-12)
+	M = MatrixFunction(T, fun="exp", deg=20, t=-1.0)
+	w, U = np.linalg.eigh(A)
+	np.testing.assert_allclose(M @ X[:, :3], (U * np.exp(-w)) @ (U.T @ X[:, :3]), rtol=1e-8, atol=1e-10)
+
+	def boom(Xt):
+		raise RuntimeError("plugin failure")
+
+	with pytest.raises(RuntimeError, match="plugin failure"):
+		quad_batch(DeviceOperator(TorchOperator(boom, 300)), X, 5, 0)
