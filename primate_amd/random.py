@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import concurrent.futures
 import multiprocessing
+import os
 from typing import Callable, Optional, Union
 
 import numpy as np
@@ -19,13 +20,53 @@ import numpy as np
 _ISO_DISTRIBUTIONS = {"rademacher": "rademacher", "normal": "normal", "sphere": "sphere", "signs": "rademacher", "gaussian": "normal"}
 
 
+_PARALLEL_MIN = 1 << 22  # elements; below this one thread is as fast
+
+
+def _signs_from_uniform(rng: np.random.Generator, flat: np.ndarray) -> None:
+	rng.random(out=flat)
+	np.multiply(flat, 2, out=flat)
+	np.floor(flat, out=flat)
+	np.multiply(flat, 2, out=flat)
+	np.subtract(flat, 1, out=flat)
+
+
+def _fill_rademacher_parallel(rng: np.random.Generator, out: np.ndarray) -> bool:
+	"""The SAME values as `_signs_from_uniform(rng, out)` drawn by several threads: `Generator.random` consumes
+	exactly one 64-bit PCG64 output per double, so a worker whose generator is a copy of `rng` advanced by `a` steps
+	produces elements [a, b) of the stream. `rng` itself is advanced by the total afterwards. Returns False (nothing
+	drawn) when the shortcut does not apply: other bit generators, non-contiguous or small outputs."""
+	bg = rng.bit_generator
+	if not isinstance(bg, np.random.PCG64) or out.size < _PARALLEL_MIN or out.dtype != np.float64:
+		return False
+	flat = out.reshape(-1) if out.flags["C_CONTIGUOUS"] else (out.T.reshape(-1) if out.flags["F_CONTIGUOUS"] else None)
+	if flat is None or not np.shares_memory(flat, out):
+		return False
+	st = bg.state
+	if st.get("has_uint32", 0):  # a buffered 32-bit half would be consumed first by integer draws only; doubles ignore it
+		pass
+	workers = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else multiprocessing.cpu_count()))
+	if workers == 1:
+		return False
+	bounds = np.linspace(0, flat.size, workers + 1).astype(np.int64)
+
+	def work(a: int, b: int) -> None:
+		g = np.random.Generator(np.random.PCG64())
+		g.bit_generator.state = st
+		g.bit_generator.advance(int(a))
+		_signs_from_uniform(g, flat[a:b])
+
+	with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+		for f in [ex.submit(work, int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]:
+			f.result()
+	bg.advance(int(flat.size))
+	return True
+
+
 def _fill(rng: np.random.Generator, pdf: str, out: np.ndarray) -> None:
 	if pdf == "rademacher":
-		rng.random(out=out)
-		np.multiply(out, 2, out=out)
-		np.floor(out, out=out)
-		np.multiply(out, 2, out=out)
-		np.subtract(out, 1, out=out)
+		if not _fill_rademacher_parallel(rng, out):
+			_signs_from_uniform(rng, out)
 	else:
 		rng.standard_normal(out=out, dtype=out.dtype)
 		if pdf == "sphere":

@@ -216,3 +216,20 @@ def test_toeplitz_plugin_operator_on_the_host():
 	np.testing.assert_allclose(Toeplitz(c) @ x, toeplitz(c) @ x, rtol=1e-12, atol=1e-12)
 	np.testing.assert_allclose(Toeplitz(c, r) @ x, toeplitz(c, r) @ x, rtol=1e-12, atol=1e-12)
 	assert is_linear_op(Toeplitz(c)) and is_valid_operator(Toeplitz(c)) == np.float64
+
+
+def test_parallel_rademacher_fill_is_the_same_stream(monkeypatch):
+	"""Large Rademacher draws are filled by several threads from PCG64 copies advanced to their offsets: the
+	values, and the state the caller's generator is left in, are those of the one-thread draw."""
+	import primate_amd.random as R
+
+	outs, tails = [], []
+	for threshold in (1 << 62, 1 << 10):
+		monkeypatch.setattr(R, "_PARALLEL_MIN", threshold)
+		rng = np.random.default_rng(99)
+		W = R.isotropic((5003, 37), pdf="rademacher", seed=rng)
+		V = R.isotropic((5003, 3), pdf="rademacher", seed=rng)  # continues the same generator
+		outs.append(np.c_[W, V])
+		tails.append(rng.random(4))
+	assert np.array_equal(outs[0], outs[1]) and np.array_equal(tails[0], tails[1])
+	assert set(np.unique(outs[1])) == {-1.0, 1.0}
