@@ -56,7 +56,7 @@ def diag(
 		done = 0
 		while done < converge.count:
 			m = min(batch, converge.count - done)
-			V = np.asfortranarray(np.column_stack([pdf_fn(size=N).reshape(N, -1) for _ in range(m)]).astype(f_dtype))
+			V = np.asfortranarray(np.column_stack([pdf_fn(size=N).reshape(N, -1) for _ in range(m)]).astype(f_dtype, copy=False))
 			plan = A._plan(m, True)
 			plan.set_probes(V)
 			plan.run(A._rtol)
@@ -78,7 +78,7 @@ def diag(
 	numer, denom = np.zeros(N, dtype=f_dtype), np.zeros(N, dtype=f_dtype)
 	result = EstimatorResult(estimator, converge)
 	while not converge(estimator):
-		v = pdf_fn(size=N).astype(f_dtype)
+		v = pdf_fn(size=N).astype(f_dtype, copy=False)
 		u = np.asarray(A @ v).ravel()
 		numer += u * v.ravel()
 		denom += np.square(v.ravel())

@@ -120,7 +120,7 @@ class MatrixFunction(LinearOperator):
 
 	def quad(self, x: np.ndarray) -> np.ndarray:
 		"""x^T f(A) x for every column of x by Lanczos quadrature (operators.py:126-151)."""
-		x = np.asarray(x).astype(self.dtype)
+		x = np.asarray(x).astype(self.dtype, copy=False)
 		x = np.atleast_2d(x).T if x.ndim == 1 else x
 		if self._stale_ring:
 			return self._quad_reference_ring(x)
@@ -170,7 +170,7 @@ class MatrixFunction(LinearOperator):
 		return self._matmat(np.asarray(x).reshape(-1, 1))
 
 	def _matmat(self, X: np.ndarray) -> np.ndarray:
-		X = np.asarray(X).astype(self.dtype)
+		X = np.asarray(X).astype(self.dtype, copy=False)
 		plan = self._plan(X.shape[1], True)
 		plan.set_probes(X)
 		plan.run(self._rtol)

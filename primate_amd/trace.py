@@ -79,7 +79,7 @@ def hutch(
 		result = EstimatorResult(estimator, converge)
 		callback = (lambda x: x) if callback is None else callback
 		while not converge(estimator):
-			estimator.update(quad_next(batch) if dev_pdf is not None else quad_form(pdf(size=(N, batch)).astype(f_dtype)))
+			estimator.update(quad_next(batch) if dev_pdf is not None else quad_form(pdf(size=(N, batch)).astype(f_dtype, copy=False)))
 			callback(result)
 		result.message = converge.message(estimator)
 		result.estimate, result.nit = estimator.estimate, len(estimator)
@@ -90,7 +90,7 @@ def hutch(
 		m = batch
 		if isinstance(converge, CountCriterion):
 			m = max(1, min(batch if not hasattr(A, "quad") else max(batch, 256), converge.count - len(estimator)))
-		ys = np.atleast_1d(quad_next(m) if dev_pdf is not None else quad_form(pdf(size=(N, m)).astype(f_dtype)))
+		ys = np.atleast_1d(quad_next(m) if dev_pdf is not None else quad_form(pdf(size=(N, m)).astype(f_dtype, copy=False)))
 		for y in ys:
 			estimator.update(y)
 			if converge(estimator):
@@ -131,7 +131,7 @@ def hutchpp(
 		result.estimate, result.nit = est, 2 * nb
 		result.samples = np.concatenate([np.ravel(rng_ests), np.ravel(defl_ests)])
 		return result.estimate, result
-	W = draw(size=(N, nb)).astype(f_dtype)
+	W = draw(size=(N, nb)).astype(f_dtype, copy=False)
 	Q = np.linalg.qr(A @ W, mode="reduced")[0]
 	if mode == "full":
 		rng_ests = np.einsum("...i,...i->...", A @ Q, Q)
@@ -140,7 +140,7 @@ def hutchpp(
 	else:
 		rng_ests = np.array([quad_form(q) for q in Q.T])
 	tr_rng = np.sum(rng_ests)
-	G = draw(size=(N, nb)).astype(f_dtype)
+	G = draw(size=(N, nb)).astype(f_dtype, copy=False)
 	G -= Q @ (Q.T @ G)
 	defl_ests = np.einsum("...i,...i->...", A @ G, G)
 	tr_defl = (1 / nb) * np.sum(defl_ests)
