@@ -12,11 +12,13 @@
  *       :92-149 (lanczos_recurrence)              -> the plan's device loop (slq_plan_run)
  *   - the operator plugin concept, src/primate/include/linear_operator.h:25-29
  *       (matvec(const F*, F*) + shape())          -> slq_operator (CSR device fast path,
- *       dense, host-callback fallback; src/primate/include/eigen_operators.h:17-104,
- *       src/primate/include/pylinop.h:16-73)
+ *       dense, host-callback fallback, GPU-resident device callback;
+ *       src/primate/include/eigen_operators.h:17-104, src/primate/include/pylinop.h:16-73)
  *   - the per-probe Python loop of MatrixFunction.quad, src/primate/operators.py:138-151,
  *       with integrate.quadrature (src/primate/integrate.py:57-76) and the LAPACK call in
- *       src/primate/tridiag.py:10-11               -> slq_quad_batch_* (one call for P probes)
+ *       src/primate/tridiag.py:10-11               -> slq_quad_batch (one call for P probes)
+ *   - MatrixFunction._matvec, src/primate/operators.py:102-124 -> slq_fAv_batch / slq_plan_fun_action
+ *   - eigh_tridiag / eigvalsh_tridiag, src/primate/tridiag.py:25-62 -> slq_eigh_tridiag_batch
  *   - random.isotropic, src/primate/random.py:22-41,47-80 -> slq_plan_generate_probes
  *   - the spectral-function registry, src/primate/special.py:78-107 -> SLQ_FUN_* ids
  *
