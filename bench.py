@@ -81,10 +81,11 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
 		r = 0 if orth == 0 else min(j + 1, orth)
 		if fused and r <= FUSED_MAX_R:
 			rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
-			# alpha pass: q_c only (q_c.q_p comes from the previous update pass's cross term), over the
-			# upper triangle of the symmetric CSR: (nnz + n) / 2 entries
-			out["spmm_3term"] += npan * ((s + 4) * (nnz + n) // 2 + 4 * (n + 1)) + vec
-			launches["spmm_3term"] += 1
+			if r == 0:
+				# alpha pass (orth = 0 only; with r >= 1 alpha comes out of the dots pass): q_c only (q_c.q_p comes
+				# from the previous update pass's cross term), over the upper triangle of the symmetric CSR
+				out["spmm_3term"] += npan * ((s + 4) * (nnz + n) // 2 + 4 * (n + 1)) + vec
+				launches["spmm_3term"] += 1
 			if r > 0:
 				out["reorth_dot"] += csr + rd * vec
 				launches["reorth_dot"] += 1

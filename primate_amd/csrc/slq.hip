@@ -958,6 +958,10 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
       (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2>,
       (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3>,
       (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2>,
@@ -1251,18 +1255,19 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
   do {                                                                                               \
     if (tiled) {                                                                                     \
+      constexpr int TP = (PASS) == PASS_ADOTS ? PASS_DOTS : (PASS); /* the tiled kernels have no merged pass */ \
       if (p->dtype == SLQ_F64)                                                                       \
-        k_csr_pass_tiled<double, PASS, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+        k_csr_pass_tiled<double, TP, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
             p->n, op->rowptr, (const double *)op->vals, op->tiles, (double *)p->ring, p->slot_stride, S, \
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
       else                                                                                           \
-        k_csr_pass_tiled<float, PASS, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+        k_csr_pass_tiled<float, TP, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
             p->n, op->rowptr, (const float *)op->vals, op->tiles, (float *)p->ring, p->slot_stride, S, \
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
     } else {                                                                                         \
       const bool half = PASS == PASS_ALPHA && op->rowptr_u != nullptr;                               \
       switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                       \
-        case 0: CSR_PASS_RC(PASS, LP, (PASS == PASS_DOTS ? 1 : 0), LDS, XT); break;                  \
+        case 0: CSR_PASS_RC(PASS, LP, ((PASS == PASS_DOTS || PASS == PASS_ADOTS) ? 1 : 0), LDS, XT); break; \
         case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                 \
         case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                 \
         case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                 \
@@ -1278,9 +1283,16 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       // XCD's L2 holds one panel's gather halo at a time (both panels side by side fetch 9.2/10.8 GB per
       // dots/update launch instead of 6.5/8.6 GB).
       const size_t fused_pad = tiled ? 0 : (size_t)env_int("SLQ_FUSED_LDS_PAD", 65536);
-      // cross term: the update pass of the previous step left W_c.W_p behind, so this alpha pass skips W_p
+      // r >= 1: alpha comes out of the dots pass (PASS_ADOTS: two gather passes per step instead of three)
+      const bool merged = !tiled && r > 0 && env_int("SLQ_MERGED", 1) != 0;
+      // cross term: the update pass of the previous step left W_c.W_p behind, so the alpha pass skips W_p
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
-      const int xt_u = (!tiled && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0;
+      const int xt_u = (!tiled && !merged && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0;
+      if (merged) {
+        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, 0); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, 0); });
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_adots, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkU, j, r, orth_tol));
+      } else {
       PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xt_a); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xt_a); });
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkF, j, xt_a));
@@ -1289,6 +1301,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st,
                                     p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
+      }
       }
       const size_t ldsU = lds0 + fused_pad + (tiled ? (size_t)r * p->PW * p->esz : 0);  // the tiled kernel stages gamma in LDS
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),

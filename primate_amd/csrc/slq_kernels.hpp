@@ -188,7 +188,13 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // RC = compile-time number of ring columns (registers); the host uses these passes
 // for r <= kFusedMaxR and the store-and-revisit sweeps (k_reorth_dot / k_reorth_update) for deeper
 // reorthogonalisation, where the saved write no longer pays for re-gathering (measured).
-enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2 };
+// PASS_ADOTS merges the alpha pass into the dots pass (r >= 1). With u = A q_c - beta q_p formed row by row,
+//   alpha = q_c.u                 and       W_t.(u - alpha q_c) = W_t.u - (alpha/nu_c) (W_t.W_c),
+// so one sweep accumulates a = (sc W_c).u, d_i = W_{t_i}.u and g_i = W_{t_i}.W_c for the ring columns
+// i = 1..RC-1 and k_fin_adots forms alpha and the projections exactly as lanczos.h:59-63,127-135 would, up to
+// rounding. Column i = 0 (W_c itself) needs no sums: q_c.(u - alpha q_c) = alpha (1 - |q_c|^2) is pure
+// rounding of alpha - in the reference too, where it stays below the 2 eps sqrt(n) threshold - so gamma_0 = 0.
+enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3 };
 
 template <typename F, int LPR, int PASS, int NTP, int RC>
 __global__ __launch_bounds__(kBlock) void k_csr_pass(
@@ -241,9 +247,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int stride = nbl * kWaves * RPW;
   VF acc1 = (VF)(F)0;  // alpha or norm partial
   VF accx = (VF)(F)0;  // cross term
-  VF dacc[RC > 0 ? RC : 1];
+  VF dacc[RC > 0 ? RC : 1], gacc[RC > 0 ? RC : 1];
 #pragma unroll
-  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = (VF)(F)0;
+  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = gacc[i] = (VF)(F)0;
   for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
     int row = r0 + g;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
@@ -282,6 +288,17 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       if (!first) w -= cp * xp;
       if (PASS == PASS_ALPHA) {
         acc1 += (sc * xc) * w;
+      } else if (PASS == PASS_ADOTS) {
+        acc1 += (sc * xc) * w;
+        if constexpr (RC > 1) {
+          dacc[1] += xp * w;
+          gacc[1] += xp * xc;
+        }
+#pragma unroll
+        for (int i = 2; i < RC; ++i) {
+          dacc[i] += u[i - 2] * w;
+          gacc[i] += u[i - 2] * xc;
+        }
       } else {
         w -= cb * xc;
         if (PASS == PASS_DOTS) {
@@ -306,6 +323,14 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
 #pragma unroll
     for (int i = 0; i < RC; ++i)
       block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+  } else if (PASS == PASS_ADOTS) {
+    // slab 0: alpha partials; slabs 1..RC-1: d_i; slabs RC..2RC-2: g_i
+    block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+#pragma unroll
+    for (int i = 1; i < RC; ++i) {
+      block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+      block_reduce_columns<F, LPR>(gacc[i], red, part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
+    }
   } else {
     block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
     if (PASS == PASS_UPDATE && xt)
@@ -900,6 +925,41 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_beta(StepState st, const do
     }
     st.coefA[col] = sc;
     st.coefA[st.bpad + col] = cp;
+  }
+}
+
+// After the merged alpha+dots pass of step j (PASS_ADOTS, RC ring columns): blockIdx.y = i.
+//   i = 0: alpha_j, cB = alpha_j / nu_j, gamma_0 = 0;
+//   i >= 1: W_t.(u - alpha q_c) = d_i - cB g_i, then the threshold and scaling of k_fin_gamma.
+__global__ __launch_bounds__(kFinThreads) void k_fin_adots(StepState st, const double *__restrict__ part, int nblk,
+                                                   int j, int RC, double orth_tol) {
+  __shared__ double red4[kFinThreads];
+  const int i = blockIdx.y;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t slab = (int64_t)nblk * st.bpad;
+  const double a = sum_partials(part, nblk, st.bpad, col, red4);
+  double d = 0.0, g = 0.0;
+  if (i > 0) {
+    d = sum_partials(part + i * slab, nblk, st.bpad, col, red4);
+    g = sum_partials(part + (RC - 1 + i) * slab, nblk, st.bpad, col, red4);
+  }
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    const int act = st.active[col];
+    const double nuj = st.nu[(int64_t)j * st.bpad + col];
+    const double cb = (act && nuj > 0.0) ? a / nuj : 0.0;
+    if (i == 0) {
+      if (act) st.alpha[(int64_t)j * st.bpad + col] = a;
+      st.coefB[col] = cb;
+      st.gamma[col] = 0.0;
+    } else {
+      const double nu = st.nu[(int64_t)(j - i) * st.bpad + col];
+      double gm = 0.0;
+      if (act && nu > 0.0) {
+        const double sproj = (d - cb * g) / nu;
+        if (fabs(sproj) > orth_tol) gm = sproj / nu;
+      }
+      st.gamma[(int64_t)i * st.bpad + col] = gm;
+    }
   }
 }
 
