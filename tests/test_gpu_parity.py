@@ -519,15 +519,16 @@ def test_opt_in_row_reordering_is_transparent(oracle, eng, monkeypatch):
 
 def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, monkeypatch):
 	"""The alpha pass gathers only the upper triangle when the stored CSR is exactly symmetric, and keeps
-	full rows otherwise: (a) symmetric operator, all three variants (upper triangle + cross term, each
-	switched off) agree with the oracle; (b) an operator that is NOT symmetric goes through the same
+	full rows otherwise: (a) symmetric operator, every launch sequence (merged alpha+dots pass; separate alpha
+	pass with the upper triangle / cross term switched on or off; store-and-revisit sweeps) agrees with the oracle; (b) an operator that is NOT symmetric goes through the same
 	arithmetic as the oracle's recurrence (lanczos.h never checks symmetry), so alpha/beta still match."""
 	A = random_spd_graph(1501, 5.0, seed=3)
 	rng = np.random.default_rng(8)
 	X = np.asfortranarray(rng.standard_normal((1501, 20)))
 	for orth in (0, 3):
 		ref = oracle.quad_batch(A, X, 18, orth, fun="log", fresh_q=True, prefer="csr")
-		for env in ({}, {"SLQ_SYM_ALPHA": "0"}, {"SLQ_CROSS": "0"}, {"SLQ_SYM_ALPHA": "0", "SLQ_CROSS": "0"}):
+		for env in ({}, {"SLQ_SYM_ALPHA": "0"}, {"SLQ_CROSS": "0"}, {"SLQ_SYM_ALPHA": "0", "SLQ_CROSS": "0"}, {"SLQ_MERGED": "0"},
+		            {"SLQ_MERGED": "0", "SLQ_CROSS": "0"}, {"SLQ_FUSED": "0"}):  # fmt: skip
 			for k, v in env.items():
 				monkeypatch.setenv(k, v)
 			op = eng.DeviceOperator(A)
