@@ -1239,7 +1239,11 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     // 0.59 -> 0.38 s at orth 3), while grids keep the passes even in natural 3-D order (2 far gathers per row:
     // 135 vs 178 ms). SLQ_FUSED=2 forces the passes.
     const bool gathers_cached = fused_mode == 2 || op->far_per_row <= 4.0;
-    if (op->kind == OP_CSR && fused && gathers_cached && r <= kFusedMaxR && !mgs) {
+    // ... with r >= 1 the merged pass can store u for the update pass to read back (SLQ_STORED_U, default on):
+    // one gather pass per step, 7 reads + 2 writes instead of the sweeps' 9 reads + 3 writes
+    const bool stored_u = op->kind == OP_CSR && fused && !gathers_cached && r >= 1 && r <= kFusedMaxR && !mgs &&
+                          env_int("SLQ_STORED_U", 1) != 0 && env_int("SLQ_MERGED", 1) != 0 && env_int("SLQ_TILES", 0) == 0;
+    if (op->kind == OP_CSR && fused && (gathers_cached || stored_u) && r <= kFusedMaxR && !mgs) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
@@ -1287,9 +1291,10 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const bool merged = !tiled && r > 0 && env_int("SLQ_MERGED", 1) != 0;
       // cross term: the update pass of the previous step left W_c.W_p behind, so the alpha pass skips W_p
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
-      const int xt_u = (!tiled && !merged && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0;
+      const int su = stored_u ? 2 : 0;
+      const int xt_u = ((!tiled && !merged && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0) | su;
       if (merged) {
-        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, 0); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, 0); });
+        PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_adots, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkU, j, r, orth_tol));
       } else {
@@ -1309,7 +1314,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
 #undef CSR_PASS
 #undef CSR_PASS_RC
       nblk_last = tiled ? p->nblkT : p->nblkU;
-      prev_xt = xt_u != 0;
+      prev_xt = (xt_u & 1) != 0;
     } else {
     prev_xt = false;
     if (op->kind == OP_CSR) {

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   // RC = number of ring columns of this step (r_j, compile time: the loops below carry no runtime guards
   // and every row's loads are issued back to back); column 0 is W_c, column 1 is W_p - the rows the
   // three-term part holds anyway - columns i >= 2 are W_{j-i}. NTP: nontemporal policy for streamed rows.
-  // xt (cross term): PASS_UPDATE also reduces X = sum_i w_{j+1}[i] w_j[i] into the second partial slab,
+  // xt bit 1 (stored u, for operators whose gathers are expensive): PASS_ADOTS also WRITES u into slot j+1 and
+  // PASS_UPDATE reads it back instead of gathering again (one gather pass per step, one extra write + read).
+  // xt bit 0 (cross term): PASS_UPDATE also reduces X = sum_i w_{j+1}[i] w_j[i] into the second partial slab,
   // and the NEXT step's PASS_ALPHA then leaves W_p unread: alpha = q_c.(A q_c) - beta (q_c.q_p) with the
   // second dot taken from X (k_fin_alpha) - one panel sweep less per step, same formula as lanczos.h.
   using VF = typename VecT<F>::type;
@@ -218,6 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int g = lane / LPR, cl = lane % LPR;
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int stored = (xt & 2) != 0;
+  xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
   const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
@@ -254,8 +258,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
     int row = r0 + g;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
     if (row < r_end) {
-      const int p0 = rowptr[row], p1 = rowptr[row + 1];
       const int64_t ro = (int64_t)row * PW;
+      const bool reuse = PASS == PASS_UPDATE && stored;  // u was stored by the merged pass: no gather
+      const int p0 = reuse ? 0 : rowptr[row], p1 = reuse ? 0 : rowptr[row + 1];
       // row-local operands first: their latency overlaps the dependent colind -> gather chain
       const VF xc = *(const VF *)(wc + ro);
       VF xp = (VF)(F)0;
@@ -286,6 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       }
       VF w = sc * acc;
       if (!first) w -= cp * xp;
+      if (reuse) w = *(const VF *)(wn + ro);
+      if (PASS == PASS_ADOTS && stored) stream_store<NTP>((VF *)(wn + ro), w);
       if (PASS == PASS_ALPHA) {
         acc1 += (sc * xc) * w;
       } else if (PASS == PASS_ADOTS) {

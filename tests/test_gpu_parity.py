@@ -555,6 +555,25 @@ def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, m
 			np.testing.assert_allclose(b[c][1:12], br[1:12], rtol=1e-9, atol=1e-9)
 
 
+def test_non_local_operator_uses_stored_u_passes(oracle, eng, monkeypatch):
+	"""A random graph whose neighbours lie all over the vector (> 4 gathers per row beyond 4096 rows): the merged
+	pass stores u and the update pass reads it back (one gather pass per step); with SLQ_STORED_U=0 the
+	store-and-revisit sweeps run instead. Both against the oracle, orth 1..4 and 0."""
+	A = random_spd_graph(20000, 12.0, seed=2)
+	rng = np.random.default_rng(6)
+	X = np.asfortranarray(rng.standard_normal((A.shape[0], 40)))
+	for orth in (0, 1, 2, 3, 4):
+		ref = oracle.quad_batch(A, X, 14, orth, fun="exp", t=-0.05, fresh_q=True, prefer="csr")
+		for env in ({}, {"SLQ_STORED_U": "0"}):
+			for k, v in env.items():
+				monkeypatch.setenv(k, v)
+			op = eng.DeviceOperator(A)
+			np.testing.assert_allclose(eng.quad_batch(op, X, 14, orth, fun="exp", t=-0.05), ref, rtol=1e-10, err_msg=f"{env} orth={orth}")
+			op.close()
+			for k in env:
+				monkeypatch.delenv(k)
+
+
 def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 	"""SLQ_TILES=1: the experimental LDS-staged fused passes (k_csr_pass_tiled) give the generic
 	passes' results to rounding, for both tile heights and with/without reorthogonalisation."""
