@@ -18,10 +18,11 @@ for o in 3 0 30; do
   echo "== kernel stats orth $o"
   rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_orth$o -o run -- python3 $B --orth $o --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_orth${o}_line_under_rocprof.json
 done
-for o in 3 0; do
+for cfg in "lap2d_1000 3" "lap2d_1000 0" "lap2d_1000 30" "lap3d_100 3"; do
+  set -- $cfg; w=$1; o=$2
   for c in FETCH_SIZE WRITE_SIZE; do
-    echo "== pmc $c orth $o"
-    rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_orth$o -o run -- python3 $B --orth $o --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
+    echo "== pmc $c $w orth $o"
+    rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_${w}_orth$o -o run -- python3 $B --workload $w --orth $o --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
   done
 done
 python3 $ROOT/scripts/summarise_pmc.py $OUT > $OUT/pmc_summary.json

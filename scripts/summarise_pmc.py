@@ -29,11 +29,11 @@ def classify(name: str, orth: int):
 
 
 summary = {}
-for orth in (3, 0):
+for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 30), ("lap3d_100", 3)):
 	per = defaultdict(lambda: defaultdict(list))
 	names = {}
 	for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-		for f in glob.glob(f"{out_dir}/pmc_{counter}_orth{orth}/**/*counter_collection.csv", recursive=True):
+		for f in glob.glob(f"{out_dir}/pmc_{counter}_{workload}_orth{orth}/**/*counter_collection.csv", recursive=True):
 			with open(f) as fh:
 				for row in csv.DictReader(fh):
 					if row.get("Counter_Name") != counter:
@@ -58,5 +58,5 @@ for orth in (3, 0):
 			"hbm_bytes_per_launch": int((2 * fa + wa) * 1024),
 			"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; check rows: gen_probes writes and probe_norm reads exactly one panel sweep (s*n*b bytes)",
 		}
-	summary[f"lap2d_1000/P256/k30/orth{orth}"] = entry
+	summary[f"{workload}/P256/k30/orth{orth}"] = entry
 json.dump(summary, sys.stdout, indent=1)
