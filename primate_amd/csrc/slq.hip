@@ -1319,9 +1319,10 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     prev_xt = false;
     if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
+      const size_t spmm_pad = (size_t)env_int("SLQ_SPMM_LDS_PAD", 57344);  // dynamic LDS only to cap residency at 2 per CU (panel after panel: 38.8 -> 34.7 ms per 26 launches at orth 30)
 #define SPMM_LAUNCH(LP, SP)                                                                          \
   DISPATCH(p->dtype, p->LPR,                                                                         \
-           (k_spmm_3term<F, L, LP, SP><<<gA, dim3(kBlock), 0, st>>>(                                 \
+           (k_spmm_3term<F, L, LP, SP><<<gA, dim3(kBlock), spmm_pad, st>>>(                          \
                p->n, op->rowptr, op->colind, (const F *)op->vals, (const F *)slot_ptr(p, sc_),       \
                (const F *)slot_ptr(p, sp_), (F *)slot_ptr(p, sn_), p->st.coefA, p->part, bp, first)))
       PROFILED(p, SLQ_K_SPMM, {
