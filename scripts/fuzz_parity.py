@@ -24,7 +24,7 @@ def random_spd(n, deg, rng):
 	return A
 
 t0 = time.time(); cases = fails = 0
-illposed_skipped = 0
+illposed_skipped = sensitive_skipped = 0
 worst = 0.0
 while time.time() - t0 < budget:
 	kind = rng.integers(0, 4)
@@ -80,6 +80,16 @@ while time.time() - t0 < budget:
 		if len(offenders) and all(ill_posed(int(c)) for c in offenders[:20]):
 			bad = False
 			illposed_skipped += 1
+		elif np.all(np.isfinite(got)) and np.all(np.isfinite(ref)):
+			## conditioning: how far does the ORACLE move when the probes change in their last bit? (partial
+			## reorthogonalisation with many steps + inv/log of small Ritz values amplifies rounding by 1e8 and more)
+			Xp = np.asfortranarray((X * (1 + np.finfo(dtype).eps * np.sign(rng.standard_normal(X.shape)))).astype(dtype))
+			refp = oracle.quad_batch(Ad, Xp, deg, orth, fun=fun, fresh_q=True, prefer="csr", **kw)
+			sens = np.max(np.abs(refp - ref) / np.maximum(np.abs(ref), 1e-300))
+			if np.nanmax(rel) <= 10.0 * sens:
+				bad = False
+				sensitive_skipped += 1
+				print(f"note: kind={kind} n={n} P={P} deg={deg} orth={orth} fun={fun}: err {np.nanmax(rel):.2e} within 10x the oracle's own 1-ulp sensitivity {sens:.2e}", flush=True)
 	if bad:
 		fails += 1
 		try:  # keep the inputs of a failing case for a post-mortem
@@ -93,5 +103,5 @@ while time.time() - t0 < budget:
 		print(f"FAIL kind={kind} n={n} nnz={A.nnz} dtype={dtype.__name__} P={P} deg={deg} orth={orth} fun={fun} err={err}", flush=True)
 	if cases % 50 == 0:
 		print(f"... {cases} cases, {fails} failures, worst fp64 rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
-print(f"done: {cases} cases, {fails} failures ({illposed_skipped} mismatches confined to near-breakdown probes not counted), worst fp64 rel err {worst:.2e}")
+print(f"done: {cases} cases, {fails} failures ({illposed_skipped} mismatches confined to near-breakdown probes and {sensitive_skipped} within 10x the oracle's own 1-ulp sensitivity not counted), worst fp64 rel err {worst:.2e}")
 sys.exit(1 if fails else 0)
