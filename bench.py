@@ -59,7 +59,7 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 	return ((s + 4) * nnz + 4 * (n + 1)) / b + (8 + 2 * r) * s * n
 
 
-FUSED_MAX_R = 4  # slq_kernels.hpp:kFusedMaxR
+FUSED_MAX_R = 8  # slq_kernels.hpp:kFusedMaxR
 
 
 def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):

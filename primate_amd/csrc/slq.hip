@@ -953,25 +953,37 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
   hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // fused passes: LDS padding caps their residency (SLQ_ALPHA_LDS_PAD experiments; dots/update: 2 per CU)
   const void *fused_fns[] = {
-      (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>,  (const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4>,   (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4>,  (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>, (const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 5>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 5>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 6>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 6>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 7>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 7>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 8>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 8>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 5>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 5>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 6>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 6>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 7>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 7>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 8>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 8>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 3>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4>};
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 5>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 5>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 6>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 6>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 7>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 7>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 8>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8>};
   for (const void *fn : fused_fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kFusedMaxR>,
-                             (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kFusedMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kFusedMaxR>,
-                             (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kFusedMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kFusedMaxR>};
+  const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kTiledMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kTiledMaxR>,
+                             (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kTiledMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kTiledMaxR>,
+                             (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kTiledMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kTiledMaxR>};
   for (const void *fn : tiled_fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
@@ -1248,7 +1260,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
       // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
-      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0;
+      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0 && p->orth <= kTiledMaxR;
       const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   DISPATCH(p->dtype, p->LPR,                                                                         \
@@ -1261,11 +1273,11 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     if (tiled) {                                                                                     \
       constexpr int TP = (PASS) == PASS_ADOTS ? PASS_DOTS : (PASS); /* the tiled kernels have no merged pass */ \
       if (p->dtype == SLQ_F64)                                                                       \
-        k_csr_pass_tiled<double, TP, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+        k_csr_pass_tiled<double, TP, LP, SP, kTiledMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
             p->n, op->rowptr, (const double *)op->vals, op->tiles, (double *)p->ring, p->slot_stride, S, \
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
       else                                                                                           \
-        k_csr_pass_tiled<float, TP, LP, SP, kFusedMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
+        k_csr_pass_tiled<float, TP, LP, SP, kTiledMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
             p->n, op->rowptr, (const float *)op->vals, op->tiles, (float *)p->ring, p->slot_stride, S, \
             j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
     } else {                                                                                         \
@@ -1275,7 +1287,11 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
         case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                 \
         case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                 \
         case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                 \
-        default: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 4), LDS, XT); break;                \
+        case 4: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 4), LDS, XT); break;                 \
+        case 5: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 5), LDS, XT); break;                 \
+        case 6: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 6), LDS, XT); break;                 \
+        case 7: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 7), LDS, XT); break;                 \
+        default: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 8), LDS, XT); break;                \
       }                                                                                              \
     }                                                                                                \
   } while (0)

@@ -55,7 +55,8 @@ constexpr int kBlock = 512;          // threads per workgroup for the sweep kern
 constexpr int kWaves = kBlock / 64;
 constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
 constexpr int kMaxDeg = 512;
-constexpr int kFusedMaxR = 4;        // fused recompute passes handle up to this many reorth columns
+constexpr int kFusedMaxR = 8;        // fused recompute passes handle up to this many reorth columns
+constexpr int kTiledMaxR = 4;        // ... and the experimental LDS-tiled variants up to this many
 #ifndef SLQ_UPD_UR
 #define SLQ_UPD_UR 2
 #endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // Ring columns t_0 = j (W_c) and t_1 = j-1 (W_p) are the rows the three-term part loads anyway.
 // RC = compile-time number of ring columns (registers); the host uses these passes
 // for r <= kFusedMaxR and the store-and-revisit sweeps (k_reorth_dot / k_reorth_update) for deeper
-// reorthogonalisation, where the saved write no longer pays for re-gathering (measured).
+// reorthogonalisation.
 // PASS_ADOTS merges the alpha pass into the dots pass (r >= 1). With u = A q_c - beta q_p formed row by row,
 //   alpha = q_c.u                 and       W_t.(u - alpha q_c) = W_t.u - (alpha/nu_c) (W_t.W_c),
 // so one sweep accumulates a = (sc W_c).u, d_i = W_{t_i}.u and g_i = W_{t_i}.W_c for the ring columns
@@ -265,11 +266,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       const VF xc = *(const VF *)(wc + ro);
       VF xp = (VF)(F)0;
       if (!first) xp = stream_load<NTP>((const VF *)(wp + ro));
+      // ring columns beyond W_c, W_p: up to two are requested before the gather chain (their latency hides behind
+      // it); with more columns the rest are loaded after it, so that their registers are not live across it
+      constexpr int NE = (PASS != PASS_ALPHA && RC > 2) ? (NX < 2 ? NX : 2) : 0;
       VF u[NX];
-      if (PASS != PASS_ALPHA && RC > 2) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) u[i] = stream_load<NTP>((const VF *)(ux[i] + ro));
-      }
+      for (int i = 0; i < NE; ++i) u[i] = stream_load<NTP>((const VF *)(ux[i] + ro));
       VF acc = (VF)(F)0;
       int p = p0;
       for (; p + 4 <= p1; p += 4) {
@@ -288,6 +290,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
         const int c = colind[p];
         const F a = vals[p];
         acc += a * *(const VF *)(wc + (int64_t)c * PW);
+      }
+      if (PASS != PASS_ALPHA && RC > 2) {
+#pragma unroll
+        for (int i = NE; i < NX; ++i) u[i] = stream_load<NTP>((const VF *)(ux[i] + ro));
       }
       VF w = sc * acc;
       if (!first) w -= cp * xp;

@@ -139,10 +139,10 @@ def test_oracle_random_graph_ragged(oracle, eng, dtype, rtol, orth):
 		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"{fun} orth={orth}")
 
 
-@pytest.mark.parametrize("orth", [1, 2, 4, 5, 6])
+@pytest.mark.parametrize("orth", [1, 2, 4, 5, 6, 7, 8, 9, 11])
 def test_every_ring_column_count(oracle, eng, orth):
-	"""The fused passes are specialised on the number of ring columns (1..4) and hand over to the
-	store-and-revisit sweeps from r = 5 on, in the middle of a run: every variant and the switch-over."""
+	"""The fused passes are specialised on the number of ring columns (1..8) and hand over to the
+	store-and-revisit sweeps from r = 9 on, in the middle of a run: every variant and the switch-over."""
 	A = random_spd_graph(1234, 7.0, seed=orth)
 	rng = np.random.default_rng(orth)
 	for dtype, rtol in [(np.float64, 1e-10), (np.float32, 3e-4)]:
