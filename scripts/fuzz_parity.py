@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
 	dtype = np.float64 if rng.random() < 0.7 else np.float32
 	P = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 257]))
 	deg = int(rng.integers(1, min(n, 40) + 1))
-	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 8, deg]))
+	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, deg]))
 	fun, kw = [("log", {}), ("exp", {"t": -0.1}), ("identity", {}), ("sqrt", {}), ("inv", {})][int(rng.integers(0, 5))]
 	Ad = A.astype(dtype)
 	X = np.asfortranarray((np.floor(rng.random((n, P)) * 2) * 2 - 1 if rng.random() < 0.5 else rng.standard_normal((n, P))).astype(dtype))
