@@ -28,16 +28,18 @@ def _launch(nproc: int, backend: str, out: Path, port: int, share_gpu0: bool):
 	return [json.load(open(f"{out}.rank{k}.json")) for k in range(nproc)]
 
 
-def test_sharded_xtrace_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("world,port", [(2, 29531), (3, 29533)])
+def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
+	"""world = 3 makes the column shards ragged (blocks of 20 -> 7, 7, 6 and the last block of 10 -> 4, 3, 3)."""
 	from primate_amd.operators import MatrixFunction
 	from primate_amd.trace import xtrace
 
 	L = laplacian_2d(40)
 	M = MatrixFunction(L, fun="exp", deg=20, orth=3, t=-0.5)
 	single = xtrace(M, batch=20, pdf="sphere", seed=7, count=50, device_rng=True)
-	res = _launch(2, "gloo", tmp_path / "g2", 29531, share_gpu0=True)
+	res = _launch(world, "gloo", tmp_path / f"g{world}", port, share_gpu0=True)
 	assert all(r["gather_ok"] and r["nit"] == 50 for r in res)
-	assert res[0]["estimate"] == res[1]["estimate"]  # replicated algebra on identical inputs
+	assert len({r["estimate"] for r in res}) == 1  # replicated algebra on identical inputs
 	## shards of 10 columns run in a narrower panel geometry than the single 20-column batch: rounding only
 	assert res[0]["estimate"] == pytest.approx(single, rel=1e-9)
 	exact = np.sum(np.exp(-0.5 * np.linalg.eigvalsh(L.toarray())))
