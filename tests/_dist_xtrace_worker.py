@@ -21,7 +21,7 @@ def main():
 	if os.environ.get("DIST_TEST_SHARE_GPU0"):
 		os.environ["LOCAL_RANK"] = "0"  # rehearsal on a 1-GPU box: every rank on device 0
 	from conftest import laplacian_2d
-	from primate_amd.distributed import allgather_columns, sharded_xtrace
+	from primate_amd.distributed import allgather_columns, sharded_diag_device, sharded_hutch_device, sharded_xtrace
 	from primate_amd.engine import DeviceMatrix
 	from primate_amd.operators import MatrixFunction
 
@@ -31,6 +31,11 @@ def main():
 	## ragged on purpose: 50 probes in blocks of 20 (20, 20, 10) over `world` ranks
 	est, info = sharded_xtrace(M, count=50, batch=20, pdf="sphere", seed=7, full=True)
 	res["estimate"], res["nit"] = float(est), int(info.nit)
+	## probe-sharded hutch and diag on the same operator: one reduction each
+	cnt, mean, var = sharded_hutch_device(M._op, 45, 20, 3, fun="exp", seed=13, t=-0.5)
+	res["hutch"] = [int(cnt), float(mean), float(var)]
+	est, numer, denom, c = sharded_diag_device(M._op, 35, 20, 3, fun="exp", seed=13, batch=8, t=-0.5)
+	res["diag"] = [int(c), float(np.sum(est)), float(np.sum(numer)), float(np.sum(denom))]
 	## the collective itself, on known data
 	n = L.shape[0]
 	S, G = DeviceMatrix(n, 3, ctx=M._op.ctx), DeviceMatrix(n, 3 * world, ctx=M._op.ctx)

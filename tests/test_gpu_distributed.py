@@ -40,6 +40,15 @@ def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
 	res = _launch(world, "gloo", tmp_path / f"g{world}", port, share_gpu0=True)
 	assert all(r["gather_ok"] and r["nit"] == 50 for r in res)
 	assert len({r["estimate"] for r in res}) == 1  # replicated algebra on identical inputs
+	## probe-sharded hutch / diag: global probe ids, so the pooled statistics equal the single-process ones
+	from primate_amd.distributed import sharded_diag_device, sharded_hutch_device
+
+	cnt, mean, var = sharded_hutch_device(M._op, 45, 20, 3, fun="exp", seed=13, t=-0.5)
+	est, numer, denom, c = sharded_diag_device(M._op, 35, 20, 3, fun="exp", seed=13, batch=8, t=-0.5)
+	for r in res:
+		assert r["hutch"][0] == cnt == 45 and r["hutch"][1] == pytest.approx(mean, rel=1e-12) and r["hutch"][2] == pytest.approx(var, rel=1e-9)
+		assert r["diag"][0] == c == 35 and r["diag"][3] == pytest.approx(float(np.sum(denom)), rel=1e-13)
+		assert r["diag"][2] == pytest.approx(float(np.sum(numer)), rel=1e-10) and r["diag"][1] == pytest.approx(float(np.sum(est)), rel=1e-10)
 	## shards of 10 columns run in a narrower panel geometry than the single 20-column batch: rounding only
 	assert res[0]["estimate"] == pytest.approx(single, rel=1e-9)
 	exact = np.sum(np.exp(-0.5 * np.linalg.eigvalsh(L.toarray())))
