@@ -14,6 +14,22 @@ import numpy as np
 from .estimators import Covariance
 
 
+def _collective_device(group, device: Optional[str]) -> str:
+	"""Tensors of a collective live on this rank's GPU for RCCL ("nccl": LOCAL_RANK, as `engine.Context` picks it)
+	and on the host for gloo."""
+	import os
+
+	import torch.distributed as dist
+
+	if device:
+		return device
+	if dist.get_backend(group) != "nccl":
+		return "cpu"
+	import torch
+
+	return f"cuda:{int(os.environ['LOCAL_RANK']) if 'LOCAL_RANK' in os.environ else torch.cuda.current_device()}"
+
+
 def shard_range(nprobes: int, rank: int, world: int) -> tuple:
 	"""Contiguous block [lo, hi) of global probe ids owned by `rank` (first ranks take the remainder)."""
 	base, rem = divmod(int(nprobes), int(world))
@@ -51,7 +67,7 @@ def allreduce_trace(samples: np.ndarray, group=None, device: Optional[str] = Non
 	import torch.distributed as dist
 
 	world = dist.get_world_size(group)
-	dev = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+	dev = _collective_device(group, device)
 	if gather_samples:
 		x = torch.as_tensor(np.asarray(samples, dtype=np.float64).ravel(), device=dev)
 		sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -75,7 +91,7 @@ def allreduce_sum(x: np.ndarray, group=None, device: Optional[str] = None) -> np
 	import torch
 	import torch.distributed as dist
 
-	dev = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+	dev = _collective_device(group, device)
 	t = torch.as_tensor(np.ascontiguousarray(x), device=dev)
 	dist.all_reduce(t, group=group)
 	return t.cpu().numpy()
