@@ -106,7 +106,8 @@ int slq_context_meminfo(slq_context *ctx, size_t *free_bytes, size_t *total_byte
  * src/primate/include/eigen_operators.h:64). */
 int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr,
                    const int32_t *colind, const void *vals, slq_operator **out);
-/* Same, arrays already on the device; borrowed for the operator's lifetime (no copy). */
+/* Same, arrays already on the device: copied device-to-device into the operator's own (padded) storage,
+ * so the caller may free them after the call. Not validated: column indices must lie in [0, n). */
 int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                           const int32_t *d_rowptr, const int32_t *d_colind, const void *d_vals,
                           slq_operator **out);

@@ -90,6 +90,29 @@ struct ProfEvent {
   int kind;
 };
 
+// Every run-time switch of the launch sequence, read from the environment ONCE, when the plan is
+// created: a plan never changes its behaviour afterwards, and key() is part of what identifies its captured hipGraph.
+struct Switches {
+  int fused;       // SLQ_FUSED     1: recompute-SpMM passes where they pay, 0: store-and-revisit sweeps, 2: passes always
+  int nt;          // SLQ_NT        nontemporal hints on streamed-once rows
+  int graph;       // SLQ_GRAPH     capture the k-step launch sequence into a hipGraph
+  int mgs;         // SLQ_MGS       exact modified-Gram-Schmidt order
+  int stored_u;    // SLQ_STORED_U  non-local operators: merged pass stores u, update pass reads it back
+  int merged;      // SLQ_MERGED    alpha from the merged alpha+dots pass
+  int cross;       // SLQ_CROSS     q_c.q_p from the update pass's cross term
+  int tiles;       // SLQ_TILES     experimental LDS row tiles
+  int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
+  int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
+  int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
+  int spmm_pad;    // SLQ_SPMM_LDS_PAD
+  unsigned key() const {
+    unsigned k = 0;
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, pipe, fused_pad, spmm_pad})
+      k = k * 1000003u + (unsigned)(v + 7);
+    return k;
+  }
+};
+
 struct slq_plan {
   slq_context *ctx;
   slq_operator *op;
@@ -121,7 +144,9 @@ struct slq_plan {
   int nstale;                 // > 0: the reorthogonalisation also sees nstale preloaded vectors t = -1 .. -nstale
   hipGraphExec_t graph_exec;  // the k-step launch sequence captured once per (plan, rtol, variant)
   double graph_rtol;
-  int graph_variant;
+  unsigned graph_variant;
+  Switches sw;
+  bool pipelined;             // dots/update passes run the pipelined row loop (slq_plan_create)
 };
 
 static int env_int(const char *name, int dflt) {
@@ -229,20 +254,18 @@ static int check_dtype(int dtype) {
 static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm) {
   perm.resize((size_t)n);
   const int64_t chunk = (n + 7) / 8;
-  std::vector<int32_t> deg((size_t)n), order, level, nbrs;
+  // Reverse Cuthill-McKee of the subgraph induced by `members` (all with part[v] == id), appended to `out`.
+  std::vector<int32_t> deg((size_t)n), part((size_t)n, -1), nbrs, order;
   std::vector<char> seen((size_t)n, 0);
-  for (int x = 0; x < 8; ++x) {
-    const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
-    if (lo >= hi) break;
-    for (int64_t i = lo; i < hi; ++i) {
+  auto rcm = [&](const std::vector<int32_t> &members, int32_t id, std::vector<int32_t> &out) {
+    for (int32_t v : members) {
       int d = 0;
-      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) d += (colind[p] >= lo && colind[p] < hi && colind[p] != i);
-      deg[(size_t)i] = d;
+      for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) d += (part[(size_t)colind[p]] == id && colind[p] != v);
+      deg[(size_t)v] = d;
     }
     order.clear();
     // candidates in increasing degree: starting points of the components
-    std::vector<int32_t> cand((size_t)(hi - lo));
-    for (int64_t i = lo; i < hi; ++i) cand[(size_t)(i - lo)] = (int32_t)i;
+    std::vector<int32_t> cand(members);
     std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
     auto bfs = [&](int32_t start, bool commit, int32_t *last_min) {
       // breadth-first numbering with neighbours in increasing degree (Cuthill-McKee)
@@ -250,7 +273,6 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       order.push_back(start);
       seen[(size_t)start] = 1;
       size_t head = base, level_begin = base;
-      int32_t far = start;
       while (head < order.size()) {
         const size_t level_end = order.size();
         level_begin = head;
@@ -259,7 +281,7 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
           nbrs.clear();
           for (int32_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
             const int32_t v = colind[p];
-            if (v >= lo && v < hi && !seen[(size_t)v]) {
+            if (part[(size_t)v] == id && !seen[(size_t)v]) {
               seen[(size_t)v] = 1;
               nbrs.push_back(v);
             }
@@ -269,7 +291,7 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
         }
       }
       // min-degree node of the last level: a pseudo-peripheral candidate
-      far = order[level_begin];
+      int32_t far = order[level_begin];
       for (size_t q = level_begin; q < order.size(); ++q)
         if (deg[(size_t)order[q]] < deg[(size_t)far]) far = order[q];
       if (last_min) *last_min = far;
@@ -284,8 +306,38 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       bfs(c, false, &far);      // one pseudo-peripheral refinement
       bfs(far, true, nullptr);
     }
-    // reverse within the chunk (RCM) and place
-    for (int64_t q = 0; q < hi - lo; ++q) perm[(size_t)(lo + q)] = order[(size_t)(hi - lo - 1 - q)];
+    for (int32_t v : members) seen[(size_t)v] = 0;
+    out.insert(out.end(), order.rbegin(), order.rend());  // reversed (RCM)
+  };
+  // Second level (SLQ_RCM_SUB = K > 1): the chunk's RCM order is cut into K consecutive pieces of equal size - runs of
+  // BFS levels, i.e. slices ACROSS the chunk's longest direction - and each piece is reordered on its own. A piece is
+  // short along the old sweep direction, so its own Cuthill-McKee levels run along another one and are K times
+  // smaller: the gather halo an XCD's L2 has to hold shrinks accordingly, at the price of the edges cut between pieces.
+  const int sub = std::max(1, env_int("SLQ_RCM_SUB", 1));
+  std::vector<int32_t> members, first, piece, second;
+  for (int x = 0; x < 8; ++x) {
+    const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    if (lo >= hi) break;
+    members.resize((size_t)(hi - lo));
+    for (int64_t i = lo; i < hi; ++i) {
+      members[(size_t)(i - lo)] = (int32_t)i;
+      part[(size_t)i] = x;
+    }
+    first.clear();
+    rcm(members, x, first);
+    if (sub > 1 && (int64_t)first.size() >= 64 * sub) {
+      second.clear();
+      const size_t len = (first.size() + sub - 1) / sub;
+      for (int k = 0; k < sub; ++k) {
+        const size_t b0 = std::min(first.size(), k * len), b1 = std::min(first.size(), b0 + len);
+        piece.assign(first.begin() + b0, first.begin() + b1);
+        const int32_t id = 8 + x * sub + k;
+        for (int32_t v : piece) part[(size_t)v] = id;
+        rcm(piece, id, second);
+      }
+      first.swap(second);
+    }
+    for (int64_t q = 0; q < hi - lo; ++q) perm[(size_t)(lo + q)] = first[(size_t)q];
   }
 }
 
@@ -492,9 +544,13 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   if (env_int("SLQ_DEBUG", 0) != 0)
     fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=%d rms in-chunk |i-j| = %.1f, far gathers per row %.2f\n", (long long)n,
             (long long)nnz, op->perm_h ? 1 : 0, op->rms_dist, op->far_per_row);
+  // colind/vals carry kCsrPad spare entries: the batched row gather (slq_kernels.hpp: gather_row_uniform)
+  // loads indices and values 8 at a time and may read (never use) up to 7 entries past a row's end
   hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, std::max<size_t>((size_t)nnz * 4, 4));
-  if (e == hipSuccess) e = hipMalloc(&op->vals, std::max<size_t>((size_t)nnz * es, 8));
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, rowptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, colind, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, vals, (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
@@ -516,8 +572,10 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
       const size_t nu = uci.size();
       op->nnz_u = (int64_t)nu;
       hipError_t ue = hipMalloc((void **)&op->rowptr_u, (size_t)(n + 1) * 4);
-      if (ue == hipSuccess) ue = hipMalloc((void **)&op->colind_u, std::max<size_t>(nu * 4, 4));
-      if (ue == hipSuccess) ue = hipMalloc(&op->vals_u, std::max<size_t>(nu * es, 8));
+      if (ue == hipSuccess) ue = hipMalloc((void **)&op->colind_u, (nu + kCsrPad) * 4);
+      if (ue == hipSuccess) ue = hipMalloc(&op->vals_u, (nu + kCsrPad) * es);
+      if (ue == hipSuccess) ue = hipMemsetAsync(op->colind_u + nu, 0, kCsrPad * 4, ctx->stream);
+      if (ue == hipSuccess) ue = hipMemsetAsync((char *)op->vals_u + nu * es, 0, kCsrPad * es, ctx->stream);
       if (ue == hipSuccess) ue = hipMemcpyAsync(op->rowptr_u, urp.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
       if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->colind_u, uci.data(), nu * 4, hipMemcpyHostToDevice, ctx->stream);
       if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->vals_u, uva.data(), nu * es, hipMemcpyHostToDevice, ctx->stream);
@@ -568,10 +626,27 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31)
     return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices");
   if (!d_rowptr || (nnz > 0 && (!d_colind || !d_vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, const_cast<int32_t *>(d_rowptr),
-                     const_cast<int32_t *>(d_colind), const_cast<void *>(d_vals), 0, false, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
+  // The kernels read colind/vals up to kCsrPad entries past nnz (gather_row_uniform), which a caller's arrays do not
+  // guarantee: the operator owns padded device-to-device copies (rowptr is copied too, so that the caller may free
+  // all three). The arrays are NOT validated (they live on the device): indices must lie in [0, n).
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
+  const size_t es = esize(dtype);
+  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, d_rowptr, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, d_colind, (size_t)nnz * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, d_vals, (size_t)nnz * es, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "device CSR copy: %s", hipGetErrorString(e));
+  }
   *out = op;
   return SLQ_OK;
 }
@@ -780,7 +855,7 @@ static int ring_slots(int deg, int orth, int keep_basis) {
   return std::max(orth + 1, 3);
 }
 
-static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nblkS, int *nblkU) {
+static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nblkS, int *nblkU, bool pipelined) {
   const int RPW = 64 / LPR;
   const int rows_per_block = kWaves * RPW;
   // Tunables: resident workgroups (kBlock threads) per CU, summed over the panels of a launch.
@@ -797,7 +872,7 @@ static void grid_sizes(int n, int LPR, int NP, int num_cus, int *nblkA, int *nbl
   // per panel. More rows in flight evict each other's gather halo
   // (dots pass, r = 3, per 30 launches: 36.3 ms at 2 resident, 41.3 at 3), and a grid that is not a multiple
   // of what is resident leaves a ragged last round. Panels run one after the other (panel-major dispatch).
-  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", 2));  // per panel
+  const int per_cu_u = std::max(1, env_int("SLQ_BLOCKS_PER_CU_FUSED", pipelined ? 1 : 2));  // per panel; 1 with the pipelined row loop
   int per_xcd_u = std::min(std::max(8, num_cus * per_cu_u) / 8, (chunk + rows_per_block - 1) / rows_per_block);
   *nblkU = 8 * std::max(per_xcd_u, 1);
   int s = std::min(std::max(1, num_cus * per_cu_s / NP), (n + rows_per_block - 1) / rows_per_block);
@@ -861,7 +936,17 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->S = ring_slots(deg, orth, p->keep_basis);
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
-  grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU);
+  p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
+                   env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
+                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_PIPE", -1),
+                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
+  // Row loop of the dots/update passes (slq_kernels.hpp: k_csr_pass). Measured on configs[1] and on the 100^3 grid
+  // (DESIGN.md §5.3): rows of up to 5 nonzeros are fastest with the plain loop at 2 resident workgroups per CU (82.9
+  // against 91.7 ms per step), 7-point rows with the pipelined loop at ONE resident workgroup per CU (93.7 against
+  // 101.0 ms): what bounds both is the traffic a CU's vector-memory pipe has in flight, and the pipelined loop puts
+  // the same bytes in flight with half the waves.
+  p->pipelined = op->kind == OP_CSR && p->LPR == 64 && (p->sw.pipe >= 0 ? p->sw.pipe != 0 : (double)op->nnz / (double)std::max<int64_t>(op->n, 1) > 5.5);
+  grid_sizes(p->n, p->LPR, p->NP, ctx->num_cus, &p->nblkA, &p->nblkS, &p->nblkU, p->pipelined);
   {
     // Fused alpha pass: one read sweep plus the gathers. Two regimes, told apart by the
     // gathers per row of the matrix the pass walks (upper triangle when the operator is symmetric):
@@ -927,7 +1012,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->weights_d = p->nodes_d + bp * (size_t)deg;
   p->graph_exec = nullptr;
   p->graph_rtol = 0.0;
-  p->graph_variant = -1;
+  p->graph_variant = 0;
   p->nstale = 0;
   {
     hipError_t ze = hipMemsetAsync(p->scal, 0, nscal * 8, ctx->stream);
@@ -952,33 +1037,111 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 template <typename F, int L> static hipError_t raise_lds_limits() {
   hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // fused passes: LDS padding caps their residency (SLQ_ALPHA_LDS_PAD experiments; dots/update: 2 per CU)
-  const void *fused_fns[] = {
-      (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0>, (const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 5>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 5>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 6>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 6>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 7>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 7>,
-      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 8>, (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 8>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 5>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 5>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 6>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 6>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 7>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 7>,
-      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 8>, (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 8>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 3>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 3>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 5>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 5>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 6>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 6>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 7>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 7>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 8>, (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8>};
+  std::vector<const void *> fused_fns = {
+      (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ALPHA, 1, 0, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 0, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_DOTS, 1, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8, 0>};
+  if constexpr (L == 64) {
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 8, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 8, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 0, 8, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_ADOTS, 1, 8, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 0, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 0, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 8, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8, 1>);
+  }
   for (const void *fn : fused_fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kTiledMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kTiledMaxR>,
@@ -992,6 +1155,10 @@ static int set_kernel_attributes(slq_plan *p) {
   hipError_t ae = hipSuccess;
   DISPATCH(p->dtype, p->LPR, (ae = raise_lds_limits<F, L>()));
   HIP_TRY(ae);
+  // (never from inside a stream capture: launch_dense_mfma runs under one)
+  HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return SLQ_OK;
 }
 
@@ -1129,7 +1296,6 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
 #define DENSE_LAUNCH(TWV, COL0)                                                                             \
   {                                                                                                         \
     const size_t lds = ((size_t)kWaves * (TWV / 16) * 4 * 64 + (size_t)TWV * 4) * sizeof(double);          \
-    HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<TWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     k_dense_mfma_3term<TWV><<<g, dim3(kBlock), lds, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc,        \
                                                         (const double *)Wp, (double *)Wn, p->st.coefA, p->part, p->bpad, first, plain, p->PW, COL0); \
   }
@@ -1148,7 +1314,7 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
 static int apply_operator_unfused(slq_plan *p, int slot_c) {
   hipStream_t st = p->ctx->stream;
   slq_operator *op = p->op;
-  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && env_int("SLQ_DENSE_MFMA", 1) != 0) {
+  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma) {
     PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, slot_c), nullptr, p->T, 1, 1, nullptr)));
     return SLQ_OK;
   }
@@ -1217,6 +1383,18 @@ static int quadrature_lanes(int deg) {
   return std::max(1, std::min(64, lanes));
 }
 
+// one fused CSR pass; the pipelined row loop exists for one-row-per-wave panels (L == 64) and not for the alpha pass
+template <typename F, int L, int PASS, int LP, int RC, typename... Args>
+static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStream_t st, Args... args) {
+  if constexpr (L == 64 && PASS != PASS_ALPHA) {
+    if (pipe_on) {
+      k_csr_pass<F, L, PASS, LP, RC, 1><<<grid, dim3(kBlock), lds, st>>>(args...);
+      return;
+    }
+  }
+  k_csr_pass<F, L, PASS, LP, RC, 0><<<grid, dim3(kBlock), lds, st>>>(args...);
+}
+
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
 static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   const bool fused = fused_mode != 0;
@@ -1244,7 +1422,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     // exact modified Gram-Schmidt order (one ring column at a time, each dot taken on the updated w):
     // used when stale ring columns take part, whose projections are NOT small, so block-CGS and the
     // reference's MGS would differ at second order (1e-6..1e-5 measured with 18 stale vectors)
-    const bool mgs = p->nstale > 0 || env_int("SLQ_MGS", 0) != 0;
+    const bool mgs = p->nstale > 0 || p->sw.mgs;
     // Recomputing the SpMM in every pass pays while the gathers are served from cache. A row whose
     // neighbours are scattered over the whole vector (random graph, 16 per row) pays an HBM row fetch per
     // gather and per pass: there the sweeps that gather once and store are 1.3-1.55x faster (configs[2]:
@@ -1254,18 +1432,18 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     // ... with r >= 1 the merged pass can store u for the update pass to read back (SLQ_STORED_U, default on):
     // one gather pass per step, 7 reads + 2 writes instead of the sweeps' 9 reads + 3 writes
     const bool stored_u = op->kind == OP_CSR && fused && !gathers_cached && r >= 1 && r <= kFusedMaxR && !mgs &&
-                          env_int("SLQ_STORED_U", 1) != 0 && env_int("SLQ_MERGED", 1) != 0 && env_int("SLQ_TILES", 0) == 0;
+                          p->sw.stored_u && p->sw.merged && !p->sw.tiles;
     if (op->kind == OP_CSR && fused && (gathers_cached || stored_u) && r <= kFusedMaxR && !mgs) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
       // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
-      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && env_int("SLQ_TILES", 0) != 0 && p->orth <= kTiledMaxR;
+      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && p->sw.tiles && p->orth <= kTiledMaxR;
       const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   DISPATCH(p->dtype, p->LPR,                                                                         \
-           (k_csr_pass<F, L, PASS, LP, RCT><<<(PASS == PASS_ALPHA ? gAf : gU), dim3(kBlock), LDS, st>>>( \
-               p->n, half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,             \
+           (launch_csr_pass<F, L, PASS, LP, RCT>(pipe_on, (PASS == PASS_ALPHA ? gAf : gU), LDS, st, p->n, \
+               half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,                   \
                (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S, j,        \
                p->st.coefA, p->st.coefB, p->st.gamma, p->part, bp, XT)))
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
@@ -1302,13 +1480,15 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       // dispatched panel-major, so panel 0 fills the chip, panel 1 follows as its workgroups retire, and an
       // XCD's L2 holds one panel's gather halo at a time (both panels side by side fetch 9.2/10.8 GB per
       // dots/update launch instead of 6.5/8.6 GB).
-      const size_t fused_pad = tiled ? 0 : (size_t)env_int("SLQ_FUSED_LDS_PAD", 65536);
+      // (the pipelined row loop runs ONE resident workgroup per CU: 96 KiB of padding)
+      const size_t fused_pad = tiled ? 0 : (size_t)(p->sw.fused_pad >= 0 ? p->sw.fused_pad : (p->pipelined ? 98304 : 65536));
+      const bool pipe_on = p->pipelined && !tiled;
       // r >= 1: alpha comes out of the dots pass (PASS_ADOTS: two gather passes per step instead of three)
-      const bool merged = !tiled && r > 0 && env_int("SLQ_MERGED", 1) != 0;
+      const bool merged = !tiled && r > 0 && p->sw.merged;
       // cross term: the update pass of the previous step left W_c.W_p behind, so the alpha pass skips W_p
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
       const int su = stored_u ? 2 : 0;
-      const int xt_u = ((!tiled && !merged && env_int("SLQ_CROSS", 1) != 0) ? 1 : 0) | su;
+      const int xt_u = ((!tiled && !merged && p->sw.cross) ? 1 : 0) | su;
       if (merged) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,
@@ -1335,7 +1515,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     prev_xt = false;
     if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
-      const size_t spmm_pad = (size_t)env_int("SLQ_SPMM_LDS_PAD", 57344);  // dynamic LDS only to cap residency at 2 per CU (panel after panel: 38.8 -> 34.7 ms per 26 launches at orth 30)
+      const size_t spmm_pad = (size_t)p->sw.spmm_pad;  // dynamic LDS only to cap residency at 2 per CU (panel after panel: 38.8 -> 34.7 ms per 26 launches at orth 30)
 #define SPMM_LAUNCH(LP, SP)                                                                          \
   DISPATCH(p->dtype, p->LPR,                                                                         \
            (k_spmm_3term<F, L, LP, SP><<<gA, dim3(kBlock), spmm_pad, st>>>(                          \
@@ -1354,7 +1534,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
 #undef SPMM_LAUNCH
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j, 0));
-    } else if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && env_int("SLQ_DENSE_MFMA", 1) != 0) {
+    } else if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma) {
       int nb = 0;
       PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, sc_), slot_ptr(p, sp_), slot_ptr(p, sn_), first, 0, &nb)));
       PROFILED(p, SLQ_K_FINALIZE,
@@ -1415,17 +1595,17 @@ extern "C" int slq_plan_run(slq_plan *p, double rtol) {
   if (!p->probes_ready) return fail(SLQ_EINVAL, "slq_plan_run: set or generate probes first");
   HIP_TRY(hipSetDevice(p->ctx->device));
   hipStream_t st = p->ctx->stream;
-  const int fused = env_int("SLQ_FUSED", 1);  // 1: recompute-SpMM passes where they pay, 0: store-and-revisit sweeps, 2: passes always
-  const bool nt = env_int("SLQ_NT", 1) != 0;         // nontemporal hints on streamed-once rows
+  const int fused = p->sw.fused;
+  const bool nt = p->sw.nt != 0;
   // The launch sequence of a run (7 launches per Lanczos step, ~210 for k = 30) depends only on
   // the plan, so it is captured into a hipGraph once and replayed: launch-bound for small n,
   // a few per cent for n = 1e6. Not used while per-kernel events are recorded, nor for host-callback
   // operators (they synchronise with the host every step).
-  const bool graph_ok = env_int("SLQ_GRAPH", 1) != 0 && !p->prof && p->op->kind != OP_CALLBACK && p->op->kind != OP_DEVICE_CALLBACK;
+  const bool graph_ok = p->sw.graph && !p->prof && p->op->kind != OP_CALLBACK && p->op->kind != OP_DEVICE_CALLBACK;
   if (!graph_ok) {
     SLQ_TRY(enqueue_run(p, rtol, fused, nt));
   } else {
-    const int variant = fused | (nt ? 4 : 0) | (p->nstale << 3);
+    const unsigned variant = p->sw.key() * 31u + (unsigned)p->nstale;  // every switch of the sequence + the stale-column count
     if (!p->graph_exec || p->graph_rtol != rtol || p->graph_variant != variant) {
       if (p->graph_exec) {
         HIP_TRY(hipGraphExecDestroy(p->graph_exec));
@@ -2226,3 +2406,22 @@ extern "C" int slq_lanczos_f32(slq_context *ctx, slq_operator *op, float *v, int
                                float *alpha, float *beta, float *Q, size_t ncv) {
   return lanczos_single<float>(ctx, op, v, deg, rtol, orth, alpha, beta, Q, ncv);
 }
+
+#ifdef SLQ_DEBUG_TIMES
+// Diagnostic build only (-DSLQ_DEBUG_TIMES, scripts/wave_drift.py): a device buffer of per-wave progress stamps.
+static unsigned long long *g_dbg_host_handle = nullptr;
+static size_t g_dbg_bytes = 0;
+extern "C" int slq_debug_times_begin(size_t bytes) {
+  if (g_dbg_host_handle) hipFree(g_dbg_host_handle);
+  HIP_TRY(hipMalloc((void **)&g_dbg_host_handle, bytes));
+  HIP_TRY(hipMemset(g_dbg_host_handle, 0, bytes));
+  g_dbg_bytes = bytes;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(slq::g_dbg_times), &g_dbg_host_handle, sizeof(void *)));
+  return SLQ_OK;
+}
+extern "C" int slq_debug_times_read(void *host, size_t bytes) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, g_dbg_host_handle, std::min(bytes, g_dbg_bytes), hipMemcpyDeviceToHost));
+  return SLQ_OK;
+}
+#endif

@@ -19,6 +19,11 @@
 
 namespace slq {
 
+#ifdef SLQ_DEBUG_TIMES
+// diagnostic build only (scripts/wave_drift.py): per-wave progress stamps of the merged dots pass
+__device__ unsigned long long *g_dbg_times = nullptr;
+#endif
+
 template <typename F> struct VecT;
 template <> struct VecT<double> {
   typedef double type __attribute__((ext_vector_type(2)));
@@ -34,21 +39,24 @@ template <> struct VecT<float> {
 // POLICY 0: plain; 1: nontemporal hint (global_load/store ... nt);
 // stores only, 2: write-through-and-drop (global_store ... sc1; MI355X_MICROARCH.md 'stores of each
 // flavour': sc1 stores do not keep the line in L2).
+// (Round 2 tried the other flavours on the streamed rows of the fused passes - sc1, sc0 sc1 and sc1 nt loads, sc1
+// and sc0 sc1 stores: none fetched less than nt, the sc1 loads 19 % more)
 template <int POLICY, typename VF> __device__ __forceinline__ VF stream_load(const VF *p) {
   if (POLICY == 1) return __builtin_nontemporal_load(p);
   return *p;
 }
-template <int POLICY> __device__ __forceinline__ void stream_store(
-    double __attribute__((ext_vector_type(2))) * p, double __attribute__((ext_vector_type(2))) v) {
+template <int POLICY, typename VF> __device__ __forceinline__ void stream_store_impl(VF *p, VF v) {
   if (POLICY == 1) __builtin_nontemporal_store(v, p);
   else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
   else *p = v;
 }
 template <int POLICY> __device__ __forceinline__ void stream_store(
+    double __attribute__((ext_vector_type(2))) * p, double __attribute__((ext_vector_type(2))) v) {
+  stream_store_impl<POLICY>(p, v);
+}
+template <int POLICY> __device__ __forceinline__ void stream_store(
     float __attribute__((ext_vector_type(4))) * p, float __attribute__((ext_vector_type(4))) v) {
-  if (POLICY == 1) __builtin_nontemporal_store(v, p);
-  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else *p = v;
+  stream_store_impl<POLICY>(p, v);
 }
 
 constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
@@ -74,6 +82,48 @@ template <typename F, int LPR> struct Geo {
   static constexpr int PW = LPR * V;   // probes per panel row
   static constexpr int RPW = 64 / LPR; // rows per wave instruction
 };
+
+// ---- CSR row gather for wave-uniform rows (one row per wave: RPW == 1) -------------------------------
+// acc = sum_k vals[p] * X[colind[p], lane's columns] over the row's nonzeros p0 <= p < p1.
+// The row is wave-uniform, so colind/vals are SCALAR loads; what bounds the gather passes is the chain of
+// dependent memory round trips per row (rowptr -> colind -> gather), not bytes. Nonzeros are therefore
+// taken in batches of 8 under a wave-uniform count mask: the whole batch's indices and values come in
+// one s_load each, and all of its gathers are in flight together. (The plain loop takes 4 at a time and
+// the remainder ONE AT A TIME, each behind an s_waitcnt vmcnt(0): 9 serialised round trips for a 7-point
+// row, 5 for a 5-point row.) The index/value loads of a batch may run up to 7 entries past the row's
+// end; they are never dereferenced. The CSR arrays carry kCsrPad spare entries for that
+// (slq.hip: slq_csr_create pads every array it uploads).
+// Summation order is p0, p0+1, ...: bitwise the same as a scalar loop over the row.
+constexpr int kCsrPad = 8;
+// 8 consecutive CSR entries as ONE scalar load each (s_load_dwordx8 / x16 need dword alignment only)
+typedef int32_t csr_i8 __attribute__((ext_vector_type(8), aligned(4)));
+typedef float csr_f8 __attribute__((ext_vector_type(8), aligned(4)));
+typedef double csr_d8 __attribute__((ext_vector_type(8), aligned(8)));
+template <typename F> struct CsrVals;
+template <> struct CsrVals<float> { typedef csr_f8 type; };
+template <> struct CsrVals<double> { typedef csr_d8 type; };
+
+template <typename F, int PW>
+__device__ __forceinline__ typename VecT<F>::type gather_row_uniform(const int32_t *__restrict__ colind,
+                                                                      const F *__restrict__ vals, int p0, int p1,
+                                                                      const F *xbase /* wave-uniform */,
+                                                                      unsigned lane_off /* elements */) {
+  using VF = typename VecT<F>::type;
+  VF acc = (VF)(F)0;
+  for (int p = p0; p < p1; p += 8) {
+    const int cnt = p1 - p;
+    const csr_i8 c = *(const csr_i8 *)(colind + p);
+    const typename CsrVals<F>::type a = *(const typename CsrVals<F>::type *)(vals + p);
+    VF x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < cnt) x[k] = *(const VF *)((xbase + (int64_t)c[k] * PW) + lane_off);  // scalar row base + lane offset
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < cnt) acc += a[k] * x[k];
+  }
+  return acc;
+}
 
 // ---- block-level column reduction -------------------------------------------------------------
 // Every lane holds V partial sums for its V columns (column = (lane % LPR) * V + v). Sum them over
@@ -139,13 +189,40 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
   const int r_end = min(n, r_begin + chunk);
   const int stride = nbl * kWaves * RPW;
   VF aacc = (VF)(F)0;
-  for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
+  constexpr bool kUniform = RPW == 1;
+  // (the wave index is wave-uniform by construction; readfirstlane tells the compiler, so that the row loop's
+  // control flow and the CSR loads become scalar)
+  const int rfirst = r_begin + (bl * kWaves + (kUniform ? __builtin_amdgcn_readfirstlane(wave) : wave)) * RPW;
+  // wave-uniform rows: the NEXT row's rowptr pair is requested while this row's gathers are in flight
+  int pn0 = 0, pn1 = 0;
+  if (kUniform && rfirst < r_end) {
+    const int rr = __builtin_amdgcn_readfirstlane(rfirst);
+    pn0 = rowptr[rr];
+    pn1 = rowptr[rr + 1];
+  }
+  for (int r0 = rfirst; r0 < r_end; r0 += stride) {
     int row = r0 + g;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
     if (row < r_end) {
-      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+      int p0, p1;
+      if (kUniform) {
+        p0 = __builtin_amdgcn_readfirstlane(pn0);
+        p1 = __builtin_amdgcn_readfirstlane(pn1);
+        const int rn = __builtin_amdgcn_readfirstlane(r0 + stride);
+        if (rn < r_end) {
+          pn0 = rowptr[rn];
+          pn1 = rowptr[rn + 1];
+        }
+      } else {
+        p0 = rowptr[row];
+        p1 = rowptr[row + 1];
+      }
       VF acc = (VF)(F)0;
       int p = p0;
+      if (kUniform) {
+        acc = gather_row_uniform<F, PW>(colind, vals, p0, p1, Wc + (int64_t)panel * n * PW, (unsigned)(cl * V));
+        p = p1;
+      }
       for (; p + 4 <= p1; p += 4) {
         const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
         const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
@@ -197,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // rounding of alpha - in the reference too, where it stays below the 2 eps sqrt(n) threshold - so gamma_0 = 0.
 enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3 };
 
-template <typename F, int LPR, int PASS, int NTP, int RC>
+template <typename F, int LPR, int PASS, int NTP, int RC, int PIPE>
 __global__ __launch_bounds__(kBlock) void k_csr_pass(
     int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
     const F *__restrict__ vals, F *ring, int64_t slot_stride, int S, int j,
@@ -225,6 +302,8 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *wcu = ring + (int64_t)(j % S) * slot_stride + (int64_t)panel * n * PW;  // wave-uniform part of wc
+  const unsigned loff = (unsigned)(cl * V);                                        // ... and the lane's part
   const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
   F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *ux[NX];
@@ -255,14 +334,63 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   VF dacc[RC > 0 ? RC : 1], gacc[RC > 0 ? RC : 1];
 #pragma unroll
   for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = gacc[i] = (VF)(F)0;
-  for (int r0 = r_begin + (bl * kWaves + wave) * RPW; r0 < r_end; r0 += stride) {
+  // ---- row loop. Two forms of the CSR side of a row (template PIPE; slq_plan_create decides per operator):
+  //  * plain (PIPE = 0): row pointers, then 4 column indices / gathers at a time, the remainder one by one;
+  //  * pipelined (PIPE = 1, one row per wave only): the row is wave-uniform, so its CSR entries are
+  //    scalar loads; the row pointers are requested two rows ahead and the first 8 column indices of the NEXT row
+  //    one row ahead, both while this row's gathers are in flight; the row's (up to) 8 gathers are issued back to
+  //    back under a count mask, and the diagonal entry is served by the row-local operand instead of a gather.
+  // Neither form changes the order in which a row's products are summed.
+  static_assert(PIPE == 0 || RPW == 1, "the pipelined row loop needs wave-uniform rows");
+  constexpr bool pipeU = PIPE != 0;
+  const bool reuse = PASS == PASS_UPDATE && stored;  // u was stored by the merged pass: no gather
+  // (the wave index is wave-uniform by construction; readfirstlane tells the compiler, so that the row loop's
+  // control flow and, with one row per wave, the CSR loads become scalar)
+  const int rfirst = r_begin + (bl * kWaves + __builtin_amdgcn_readfirstlane(wave)) * RPW;
+  using A8 = typename CsrVals<F>::type;
+  int pn0 = 0, pn1 = 0, pq0 = 0, pq1 = 0;  // row pointers of the next row and of the one after it
+  csr_i8 cn = (csr_i8)0;                   // first 8 column indices of the next row
+  if (pipeU && !reuse) {
+    const int rr = rfirst, rq = rr + stride;
+    if (rr < r_end) {
+      pn0 = rowptr[rr];
+      pn1 = rowptr[rr + 1];
+    }
+    if (rq < r_end) {
+      pq0 = rowptr[rq];
+      pq1 = rowptr[rq + 1];
+    }
+    cn = *(const csr_i8 *)(colind + pn0);
+  }
+#ifdef SLQ_DEBUG_TIMES
+  int dbg_q = 0, dbg_rows = 0;
+  unsigned long long *dbg = (PASS == PASS_ADOTS && g_dbg_times)
+                                ? g_dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 8
+                                : nullptr;
+#endif
+  for (int r0 = rfirst; r0 < r_end; r0 += stride) {
+#ifdef SLQ_DEBUG_TIMES
+    if (dbg && lane == 0) {
+      const int q = (int)(((int64_t)(r0 - r_begin) * 4) / (r_end - r_begin));
+      if (dbg_rows == 0 || q > dbg_q) dbg[q < 4 ? q : 3] = __builtin_amdgcn_s_memrealtime();
+      dbg_q = q;
+    }
+    ++dbg_rows;
+#endif
     int row = r0 + g;
     if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
     if (row < r_end) {
       const int64_t ro = (int64_t)row * PW;
-      const bool reuse = PASS == PASS_UPDATE && stored;  // u was stored by the merged pass: no gather
-      const int p0 = reuse ? 0 : rowptr[row], p1 = reuse ? 0 : rowptr[row + 1];
-      // row-local operands first: their latency overlaps the dependent colind -> gather chain
+      int p0 = 0, p1 = 0;
+      const csr_i8 c8 = cn;
+      if (pipeU) {
+        p0 = __builtin_amdgcn_readfirstlane(pn0);
+        p1 = __builtin_amdgcn_readfirstlane(pn1);
+      } else if (!reuse) {
+        p0 = rowptr[row];
+        p1 = rowptr[row + 1];
+      }
+      // row-local operands first: their latency overlaps the gathers
       const VF xc = *(const VF *)(wc + ro);
       VF xp = (VF)(F)0;
       if (!first) xp = stream_load<NTP>((const VF *)(wp + ro));
@@ -274,6 +402,48 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       for (int i = 0; i < NE; ++i) u[i] = stream_load<NTP>((const VF *)(ux[i] + ro));
       VF acc = (VF)(F)0;
       int p = p0;
+      if (pipeU) {
+        // batches of 8 nonzeros; the first batch's column indices are already in SGPRs (requested one row ago)
+        csr_i8 cb = c8;
+        for (int pb = p0; pb < p1; pb += 8) {
+          const int cnt = p1 - pb;
+          // live = entries to gather; the diagonal entry's panel row is xc (substituted at the multiply, not at
+          // the load, so that no gather waits for it)
+          unsigned live = cnt >= 8 ? 0xffu : ((1u << cnt) - 1u);
+          unsigned diag = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) diag |= (cb[k] == row ? 1u : 0u) << k;
+          diag &= live;
+          live &= ~diag;
+          VF x[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (live & (1u << k)) x[k] = *(const VF *)((wcu + (int64_t)cb[k] * PW) + loff);
+          // with the gathers in flight: this batch's values (needed only when the gathers are back) and, once
+          // per row, the next row's indices and the row pointers after it
+          const A8 a8 = *(const A8 *)(vals + pb);
+          if (pb == p0) {
+            pn0 = pq0;
+            pn1 = pq1;
+            cn = *(const csr_i8 *)(colind + pq0);
+            const int rn2 = r0 + 2 * stride;
+            if (!reuse && rn2 < r_end) {
+              pq0 = rowptr[rn2];
+              pq1 = rowptr[rn2 + 1];
+            }
+            // pin the request HERE, behind the gathers' issue and ahead of their wait (the optimiser otherwise
+            // sinks it to the loop latch, i.e. behind the wait, and the next row starts with an exposed s_load)
+            asm volatile("" : "+s"(cn));
+          }
+          if (cnt > 8) cb = *(const csr_i8 *)(colind + pb + 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (live & (1u << k)) acc += a8[k] * x[k];
+            else if (diag & (1u << k)) acc += a8[k] * xc;
+          }
+        }
+        p = p1;
+      }
       for (; p + 4 <= p1; p += 4) {
         const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
         const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
@@ -331,6 +501,14 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       }
     }
   }
+#ifdef SLQ_DEBUG_TIMES
+  if (dbg && lane == 0) {
+    dbg[4] = __builtin_amdgcn_s_memrealtime();
+    dbg[5] = (unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);  // HW_REG_XCC_ID
+    dbg[6] = (unsigned long long)dbg_rows;
+    dbg[7] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 32);
+  }
+#endif
   const int64_t nblk = gridDim.x;
   if (PASS == PASS_DOTS) {
 #pragma unroll
