@@ -108,6 +108,162 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
 	return out, launches
 
 
+def pmc_traffic(workload, P, deg, orth, dom):
+	"""HBM bytes per launch of kernel class `dom` from the committed PMC summary (scripts/collect_profiles.sh ->
+	scripts/summarise_pmc.py), and where that number comes from. The counters are collected in their own rocprofv3
+	passes, not in this run: the summary records the sha256 of the kernel sources it was measured on, and a summary
+	taken on other sources yields traffic = None."""
+	pmc = ROOT / "profiles" / "pmc_summary.json"
+	if not pmc.exists():
+		return None, None
+	try:
+		rec = json.loads(pmc.read_text())
+	except Exception:  # noqa: BLE001
+		return None, None
+	meta = rec.get("_meta", {})
+	src = {"file": "profiles/pmc_summary.json", "tag": meta.get("tag"), "kernel_sha256": meta.get("kernel_sha256"), "current": True}
+	if meta.get("kernel_sha256") != kernel_sources_sha256():
+		src["current"] = False
+		return None, src
+	return rec.get(f"{workload}/P{P}/k{deg}/orth{orth}", {}).get(dom, {}).get("hbm_bytes_per_launch"), src
+
+
+def kernel_sources_sha256():
+	import hashlib
+
+	h = hashlib.sha256()
+	for f in ("primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq.hip"):
+		h.update((ROOT / f).read_bytes())
+	return h.hexdigest()
+
+
+def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank, world, dist, red_dev, profiled=True, stream_rates=True):
+	"""One bench measurement: `warmup` untimed + `steps` timed passes of the hot path on `workload`; returns the JSON line."""
+	import torch
+
+	from primate_amd.engine import DeviceOperator, LanczosPlan
+
+	kind, m = workload.split("_")
+	np_dt = np.float64 if dtype == "f64" else np.float32
+	A = laplacian_2d(int(m), dtype=np_dt) if kind == "lap2d" else laplacian_3d(int(m), dtype=np_dt)
+	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
+	op = DeviceOperator(A, ctx=ctx)  # CSR resident in HBM before the timed region
+	deg = min(deg_req, n)
+	orth = deg if orth_req < 0 or orth_req > deg else orth_req
+	plan = LanczosPlan(op, P, deg, orth)
+
+	def step(it: int):
+		## probe ids are global: rank r draws ids [ (it*world + r) * P, ... + P )
+		plan.generate_probes("rademacher", seed=1234, probe_offset=(it * world + rank) * P)
+		plan.run(1e-8)
+		q = plan.quadrature(fun)  # device QL + reduction; returns P doubles (synchronises)
+		if dist is not None:
+			st = torch.tensor([q.sum(), (q * q).sum(), float(len(q))], dtype=torch.float64, device=red_dev)
+			dist.all_reduce(st)  # RCCL over xGMI: the only collective on the path
+			return st
+		return q
+
+	def barrier():
+		if dist is not None:
+			dist.barrier()
+		torch.cuda.synchronize()
+		ctx.synchronize()
+
+	for it in range(warmup):
+		step(it)
+	## per-kernel HIP events over the timed region (the roofline object needs them); BENCH_NO_PROFILE=1 times the
+	## same steps without them (hipGraph replay) to show what the instrumentation costs
+	plan.profile_enable(profiled)
+	plan.profile_read(reset=True)
+	barrier()
+	t0 = time.perf_counter()
+	ests = []
+	for it in range(steps):
+		out = step(warmup + it)
+		ests.append(out)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if dist is not None:
+		tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+		elapsed = float(tmax.item())
+	prof_steps = steps
+	if not profiled:  # A/B mode: kernel events from ONE extra step outside the timed region
+		plan.profile_enable(True)
+		plan.profile_read(reset=True)
+		step(warmup + steps)
+		barrier()
+		prof_steps = 1
+	prof = plan.profile_read(reset=True)
+	plan.profile_enable(False)
+
+	if dist is not None:
+		tot = torch.stack(ests).sum(0).cpu().numpy()
+		estimate = tot[0] / tot[2]
+	else:
+		estimate = float(np.mean(np.concatenate(ests)))
+
+	probe_matvecs = world * P * deg * steps
+	value = probe_matvecs / elapsed
+	ms_per_step = elapsed / steps * 1e3
+
+	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
+	vlen = 16 // s  # probes per lane (16-byte loads)
+	pw = next(l * vlen for l in (8, 16, 32, 64) if l * vlen >= P or l == 64)
+	fused = os.environ.get("SLQ_FUSED", "1") != "0"
+	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, fused=fused)
+	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
+	dom = max(cand, key=cand.get)
+	launches = prof[dom]["launches"]
+	avg_ms = prof[dom]["ms"] / launches
+	alg_bytes_per_launch = kb[dom] / kl[dom]
+	achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+	traffic, traffic_source = pmc_traffic(workload, P, deg, orth, dom)
+	## the rate this card actually sustains for the sweeps' access shape (SURVEY.md §8d asks for both)
+	measured = {m: round(ctx.measure_stream(m, nbytes=1 << 31, reps=5), 1) for m in ("read", "triad")} if stream_rates else None
+	roofline = {
+		"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+		"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+		"measured_stream_GBps": measured, "frac_of_measured_triad": round(achieved / measured["triad"], 4) if measured else None,
+		"alg_bytes_per_launch": int(alg_bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
+	}  # fmt: skip
+	## whole-loop view: SURVEY §8(d) contract bytes per probe-matvec / wall time of the step
+	contract = sum(contract_bytes_per_probe_matvec(n, nnz, s, P, j, orth) for j in range(deg)) / deg
+	kernels = {
+		k: {
+			"ms_per_step": round(prof[k]["ms"] / prof_steps, 3),
+			"launches_per_step": prof[k]["launches"] / prof_steps,
+			**({"alg_GBps": round(kb[k] * prof_steps / (prof[k]["ms"] * 1e-3) / 1e9, 1)} if k in kb and prof[k]["ms"] > 0 else {}),
+		}
+		for k in prof
+		if prof[k]["launches"] > 0
+	}
+
+	line = {
+		"metric": "probe-matvecs/sec", "value": round(value, 1), "unit": "probe-matvecs/s", "n_gpus": world,
+		"steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+		"scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+		"config": {
+			"workload": f"{'configs[1]: logdet via SLQ' if workload == 'lap2d_1000' and dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={fun}",
+			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
+			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused),
+			"kernel_events_in_timed_region": bool(profiled),
+		},
+		"trace_estimates_per_s": round(world * P * steps / elapsed, 1),
+		"estimate": float(estimate),
+		"roofline": roofline,
+		"loop": {
+			"contract_bytes_per_probe_matvec": int(contract),
+			"contract_GBps_per_gpu": round(value / world * contract / 1e9, 1),
+			"contract_frac_of_peak": round(value / world * contract / 1e9 / HBM_PEAK_GBS, 4),
+		},
+		"kernels": kernels,
+	}  # fmt: skip
+
+	del plan, op
+	return {"line": line, "A": A, "n": n, "deg": deg, "orth": orth}
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +276,7 @@ def main():
 	ap.add_argument("--fun", default="log")
 	ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="arithmetic type of the operator and the Lanczos vectors")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-extra", action="store_true", help="skip the extra operators appended to the default line")
 	ap.add_argument("--cpu-seconds", type=float, default=15.0)
 	args = ap.parse_args()
 
@@ -149,134 +306,43 @@ def main():
 		else:
 			dist.init_process_group(backend, rank=rank, world_size=world)
 
-	from primate_amd.engine import Context, DeviceOperator, LanczosPlan
+	from primate_amd.engine import Context
 
-	kind, m = args.workload.split("_")
-	np_dt = np.float64 if args.dtype == "f64" else np.float32
-	A = laplacian_2d(int(m), dtype=np_dt) if kind == "lap2d" else laplacian_3d(int(m), dtype=np_dt)
-	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
 	ctx = Context(device=local_rank)
-	op = DeviceOperator(A, ctx=ctx)  # CSR resident in HBM before the timed region
-	P, deg = args.probes, min(args.deg, n)
-	orth = deg if args.orth < 0 or args.orth > deg else args.orth
-	plan = LanczosPlan(op, P, deg, orth)
+	res = measure(ctx, args.workload, args.dtype, args.probes, args.deg, args.orth, args.steps, args.warmup, args.fun,
+				  rank, world, dist, red_dev, profiled=not os.environ.get("BENCH_NO_PROFILE"))
+	line, A, n, deg, orth = res["line"], res["A"], res["n"], res["deg"], res["orth"]
+	line["steps"], line["warmup"] = args.steps, args.warmup
 
-	def step(it: int):
-		## probe ids are global: rank r draws ids [ (it*world + r) * P, ... + P )
-		plan.generate_probes("rademacher", seed=1234, probe_offset=(it * world + rank) * P)
-		plan.run(1e-8)
-		q = plan.quadrature(args.fun)  # device QL + reduction; returns P doubles (synchronises)
-		if dist is not None:
-			st = torch.tensor([q.sum(), (q * q).sum(), float(len(q))], dtype=torch.float64, device=red_dev)
-			dist.all_reduce(st)  # RCCL over xGMI: the only collective on the path
-			return st
-		return q
-
-	def barrier():
-		if dist is not None:
-			dist.barrier()
-		torch.cuda.synchronize()
-		ctx.synchronize()
-
-	for it in range(args.warmup):
-		step(it)
-	## per-kernel HIP events over the timed region (the roofline object needs them); BENCH_NO_PROFILE=1 times the
-	## same steps without them (hipGraph replay) to show what the instrumentation costs
-	profiled = not os.environ.get("BENCH_NO_PROFILE")
-	plan.profile_enable(profiled)
-	plan.profile_read(reset=True)
-	barrier()
-	t0 = time.perf_counter()
-	ests = []
-	for it in range(args.steps):
-		out = step(args.warmup + it)
-		ests.append(out)
-	barrier()
-	elapsed = time.perf_counter() - t0
+	## ---- what a reader needs to verify an N-rank run: backend, world size, one distinct device per rank
 	if dist is not None:
-		tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-		elapsed = float(tmax.item())
-	prof_steps = args.steps
-	if not profiled:  # A/B mode: kernel events from ONE extra step outside the timed region
-		plan.profile_enable(True)
-		plan.profile_read(reset=True)
-		step(args.warmup + args.steps)
-		barrier()
-		prof_steps = 1
-	prof = plan.profile_read(reset=True)
-	plan.profile_enable(False)
+		prop = torch.cuda.get_device_properties(local_rank)
+		mine = {
+			"rank": rank, "local_rank": local_rank, "name": prop.name,
+			"pci": f"{getattr(prop, 'pci_domain_id', 0):04x}:{getattr(prop, 'pci_bus_id', -1):02x}:{getattr(prop, 'pci_device_id', 0):02x}",
+			"uuid": str(getattr(prop, "uuid", "")),
+		}  # fmt: skip
+		devs = [None] * world
+		dist.all_gather_object(devs, mine)
+		line["rccl"] = {"backend": dist.get_backend(), "world": world, "devices": devs}
+		if dist.get_backend() == "nccl" and "BENCH_DEVICE" not in os.environ:
+			ids = {(d["pci"], d["uuid"]) for d in devs}
+			assert len(ids) == world, f"ranks share a GPU: {devs}"
 
-	if dist is not None:
-		tot = torch.stack(ests).sum(0).cpu().numpy()
-		estimate = tot[0] / tot[2]
-	else:
-		estimate = float(np.mean(np.concatenate(ests)))
-
-	probe_matvecs = world * P * deg * args.steps
-	value = probe_matvecs / elapsed
-	ms_per_step = elapsed / args.steps * 1e3
-
-	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
-	vlen = 16 // s  # probes per lane (16-byte loads)
-	pw = next(l * vlen for l in (8, 16, 32, 64) if l * vlen >= P or l == 64)
-	fused = os.environ.get("SLQ_FUSED", "1") != "0"
-	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, fused=fused)
-	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
-	dom = max(cand, key=cand.get)
-	launches = prof[dom]["launches"]
-	avg_ms = prof[dom]["ms"] / launches
-	alg_bytes_per_launch = kb[dom] / kl[dom]
-	achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-	traffic = None
-	pmc = ROOT / "profiles" / "pmc_summary.json"
-	if pmc.exists():
-		try:
-			rec = json.loads(pmc.read_text())
-			key = f"{args.workload}/P{P}/k{deg}/orth{orth}"
-			traffic = rec.get(key, {}).get(dom, {}).get("hbm_bytes_per_launch")
-		except Exception:  # noqa: BLE001
-			traffic = None
-	## the rate this card actually sustains for the sweeps' access shape (SURVEY.md §8d asks for both)
-	measured = {m: round(ctx.measure_stream(m, nbytes=1 << 31, reps=5), 1) for m in ("read", "triad")}
-	roofline = {
-		"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-		"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-		"measured_stream_GBps": measured, "frac_of_measured_triad": round(achieved / measured["triad"], 4),
-		"alg_bytes_per_launch": int(alg_bytes_per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-	}  # fmt: skip
-	## whole-loop view: SURVEY §8(d) contract bytes per probe-matvec / wall time of the step
-	contract = sum(contract_bytes_per_probe_matvec(n, nnz, s, P, j, orth) for j in range(deg)) / deg
-	kernels = {
-		k: {
-			"ms_per_step": round(prof[k]["ms"] / prof_steps, 3),
-			"launches_per_step": prof[k]["launches"] / prof_steps,
-			**({"alg_GBps": round(kb[k] * prof_steps / (prof[k]["ms"] * 1e-3) / 1e9, 1)} if k in kb and prof[k]["ms"] > 0 else {}),
-		}
-		for k in prof
-		if prof[k]["launches"] > 0
-	}
-
-	line = {
-		"metric": "probe-matvecs/sec", "value": round(value, 1), "unit": "probe-matvecs/s", "n_gpus": world,
-		"steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-		"scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-		"config": {
-			"workload": f"{'configs[1]: logdet via SLQ' if args.workload == 'lap2d_1000' and args.dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={args.fun}",
-			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
-			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused),
-			"kernel_events_in_timed_region": bool(profiled),
-		},
-		"trace_estimates_per_s": round(world * P * args.steps / elapsed, 1),
-		"estimate": float(estimate),
-		"roofline": roofline,
-		"loop": {
-			"contract_bytes_per_probe_matvec": int(contract),
-			"contract_GBps_per_gpu": round(value / world * contract / 1e9, 1),
-			"contract_frac_of_peak": round(value / world * contract / 1e9 / HBM_PEAK_GBS, 4),
-		},
-		"kernels": kernels,
-	}  # fmt: skip
+	## ---- the other operators of BASELINE.md §2 in the same record (N = 1, default invocation only): the north_star's
+	## 3-D 100^3 operator (nnz = 6.94 M) at the default and at no reorthogonalisation, and configs[1] at orth = 0
+	default_run = args.workload == "lap2d_1000" and args.dtype == "f64" and args.orth == 3 and args.probes == 256 and args.deg == 30
+	if rank == 0 and world == 1 and default_run and not args.no_extra:
+		extra = {}
+		for key, (w, o) in {"lap3d_100_orth3": ("lap3d_100", 3), "lap3d_100_orth0": ("lap3d_100", 0), "lap2d_1000_orth0": ("lap2d_1000", 0)}.items():
+			r = measure(ctx, w, "f64", 256, 30, o, 3, 1, args.fun, 0, 1, None, red_dev, profiled=True, stream_rates=False)["line"]
+			extra[key] = {
+				"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+				"workload": r["config"]["workload"], "nnz": r["config"]["nnz"], "estimate": r["estimate"],
+				"roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "alg_bytes_per_launch", "avg_launch_ms", "launches")},
+				"kernels": r["kernels"],
+			}  # fmt: skip
+		line["extra"] = extra
 
 	## ---- CPU baseline: the oracle (C restatement of the reference kernel), rank 0, N = 1 only ---
 	if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -99,6 +99,8 @@ int slq_context_destroy(slq_context *ctx);
 int slq_context_synchronize(slq_context *ctx);
 /* bytes free / total on the context's device */
 int slq_context_meminfo(slq_context *ctx, size_t *free_bytes, size_t *total_bytes);
+/* the HIP device ordinal the context is bound to (device = -1 at creation resolves to the current device) */
+int slq_context_device(slq_context *ctx, int *device);
 
 /* ---- operators ------------------------------------------------------------------------------ */
 /* CSR, int32 indices, host arrays: copied to the device once (the reference copies the matrix

@@ -50,6 +50,7 @@ _SIGNATURES = {
 	"slq_context_destroy": (C.c_int, [_P]),
 	"slq_context_synchronize": (C.c_int, [_P]),
 	"slq_context_meminfo": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+	"slq_context_device": (C.c_int, [_P, C.POINTER(C.c_int)]),
 	"slq_csr_create": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, _PP]),
 	"slq_csr_create_device": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, _PP]),
 	"slq_dense_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, C.c_int64, _PP]),

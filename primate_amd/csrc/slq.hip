@@ -83,6 +83,7 @@ struct slq_operator {
   double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
   int64_t nnz_u = 0;       // entries of the upper-triangle copy
   double far_per_row = 0.0;  // stored nonzeros per row with |i - j| > 4096 (0 when unknown: device-resident CSR)
+  void *vals_t = nullptr;    // OP_DENSE, non-symmetric input only: the transpose, for the kernel that walks A by columns (null: A == A^T)
 };
 
 struct ProfEvent {
@@ -214,6 +215,12 @@ extern "C" int slq_context_synchronize(slq_context *ctx) {
   if (!ctx) return fail(SLQ_EINVAL, "ctx is NULL");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SLQ_OK;
+}
+
+extern "C" int slq_context_device(slq_context *ctx, int *device) {
+  if (!ctx || !device) return fail(SLQ_EINVAL, "ctx/device is NULL");
+  *device = ctx->device;
   return SLQ_OK;
 }
 
@@ -662,10 +669,30 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   const size_t es = esize(dtype);
+  // Y = A X for whatever is given (eigen_operators.h:24-30 does not ask for symmetry either). k_dense_mfma_3term reads
+  // A(row, k) and is right for any A; k_dense_panel walks row `row` of A as the contiguous COLUMN `row`, which is A^T:
+  // equal for the symmetric operators Lanczos is meant for. An O(n^2) host pass checks that; a non-symmetric input
+  // gets its transpose uploaded next to it for that kernel.
+  bool symmetric = true;
+  for (int64_t j = 0; j < n && symmetric; ++j)
+    for (int64_t i = j + 1; i < n; ++i) {
+      const bool same = dtype == SLQ_F64 ? ((const double *)A)[j * lda + i] == ((const double *)A)[i * lda + j]
+                                         : ((const float *)A)[j * lda + i] == ((const float *)A)[i * lda + j];
+      if (!same) { symmetric = false; break; }
+    }
   hipError_t e = hipMalloc(&op->vals, (size_t)n * n * es);
   if (e == hipSuccess)
     e = hipMemcpy2DAsync(op->vals, (size_t)n * es, A, (size_t)lda * es, (size_t)n * es, (size_t)n,
                          hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && !symmetric) {
+    std::vector<char> T((size_t)n * n * es);
+    for (int64_t j = 0; j < n; ++j)
+      for (int64_t i = 0; i < n; ++i)
+        memcpy(T.data() + ((size_t)j * n + i) * es, (const char *)A + ((size_t)i * lda + j) * es, es);  // T(i,j) = A(j,i)
+    e = hipMalloc(&op->vals_t, (size_t)n * n * es);
+    if (e == hipSuccess) e = hipMemcpyAsync(op->vals_t, T.data(), (size_t)n * n * es, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     slq_operator_destroy(op);
@@ -711,6 +738,7 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
     if (op->colind) hipFree(op->colind);
     if (op->vals) hipFree(op->vals);
   }
+  if (op->vals_t) hipFree(op->vals_t);
   if (op->perm_d) hipFree(op->perm_d);
   delete op->perm_h;
   if (op->rowptr_u) hipFree(op->rowptr_u);
@@ -1323,7 +1351,7 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
     PROFILED(p, SLQ_K_SPMM,
              DISPATCH(p->dtype, p->LPR,
                       (k_dense_panel<F, L><<<g, dim3(kBlock), 0, st>>>(p->n,
-                                          (const F *)op->vals, op->lda, (const F *)slot_ptr(p, slot_c), (F *)p->T))));
+                                          (const F *)(op->vals_t ? op->vals_t : op->vals), op->lda, (const F *)slot_ptr(p, slot_c), (F *)p->T))));
     return SLQ_OK;
   }
   if (op->kind == OP_DEVICE_CALLBACK) {

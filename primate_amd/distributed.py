@@ -97,22 +97,76 @@ def allreduce_sum(x: np.ndarray, group=None, device: Optional[str] = None) -> np
 	return t.cpu().numpy()
 
 
-def sharded_hutch_device(op, nprobes: int, deg: int, orth: int, fun="identity", pdf: str = "rademacher", seed: int = 0, rtol: float = 1e-8, group=None, **fun_kwargs):
-	"""hutch() with a fixed probe budget, probes drawn on the device and sharded over the ranks of
-	`group`. Global probe ids make the per-probe values independent of the number of GPUs."""
+def sharded_hutch(evaluate, converge="default", batch: int = 32, group=None, full: bool = False, record: bool = False, callback=None, **kwargs):
+	"""hutch() with an adaptive stopping rule over probe-sharded ranks (SURVEY.md §8e "Early stopping"): batch-synchronous.
+	Every GLOBAL batch of `batch` probe ids [done, done + batch) is cut into contiguous per-rank blocks;
+	`evaluate(lo, hi)` returns this rank's per-probe values for global ids [lo, hi); ONE all-gather per batch brings the
+	values of all ranks together in id order, every rank folds them into its own copy of the estimator with
+	`MeanEstimator.update` - the same call, on the same numbers, in the same order as the single-process
+	`hutch(..., full=True)` makes per batch (src/primate/trace.py:104-110) - and evaluates the criterion on it, so all
+	ranks stop at the same batch with the same estimate. `converge` / kwargs as in `hutch` (default: 200 samples or a
+	95 % confidence interval of half-width 1, trace.py:89-92)."""
+	import torch.distributed as dist
+
+	from .estimators import ConfidenceCriterion, CountCriterion, EstimatorResult, MeanEstimator, convergence_criterion
+
+	rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+	estimator = MeanEstimator(covariance=True, record=record)
+	if isinstance(converge, str) and converge == "default":
+		crit = CountCriterion(count=200) | ConfidenceCriterion(confidence=0.95, atol=1.0, rtol=0.0)
+	else:
+		crit = convergence_criterion(converge, **kwargs)
+	result = EstimatorResult(estimator, crit)
+	done = 0
+	while not crit(estimator):
+		lo, hi = shard_range(batch, rank, world)
+		q = np.asarray(evaluate(done + lo, done + hi), dtype=np.float64).ravel() if hi > lo else np.zeros(0)
+		assert q.size == hi - lo
+		allq = q if world == 1 else allreduce_trace(q, group=group, gather_samples=True)[3]
+		estimator.update(allq)
+		done += batch
+		if callback is not None:
+			callback(result)
+	result.message = crit.message(estimator)
+	result.estimate, result.nit = estimator.estimate, len(estimator)
+	return (estimator.estimate, result) if full else estimator.estimate
+
+
+def sharded_hutch_device(op, nprobes: Optional[int] = None, deg: int = 20, orth: int = 3, fun="identity", pdf: str = "rademacher", seed: int = 0, rtol: float = 1e-8,
+						 group=None, converge=None, batch: int = 32, full: bool = False, converge_kwargs: Optional[dict] = None, **fun_kwargs):  # fmt: skip
+	"""hutch() with probes drawn on the device and sharded over the ranks of `group`. Global probe ids make the
+	per-probe values independent of the number of GPUs.
+	  * converge=None: fixed budget of `nprobes`, one all-gather of (count, mean, M2) at the end; returns
+	    (count, mean, sample variance);
+	  * converge="default" | "count" | "confidence" | "tolerance" | "knee" | a criterion: adaptive stopping,
+	    evaluated per global batch of `batch` probes on the merged estimator (`sharded_hutch`); returns what
+	    `hutch` returns (the estimate, or (estimate, EstimatorResult) with full=True). `converge_kwargs` are the
+	    criterion's arguments (count, confidence, atol, rtol, ...)."""
 	import torch.distributed as dist
 
 	from .engine import LanczosPlan
 
 	rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-	lo, hi = shard_range(nprobes, rank, world)
-	q = np.zeros(0)
-	if hi > lo:
-		plan = LanczosPlan(op, hi - lo, deg, orth)
+	plans = {}
+
+	def evaluate(lo: int, hi: int) -> np.ndarray:
+		m = hi - lo
+		if m not in plans:
+			plans[m] = LanczosPlan(op, m, deg, orth)
+		plan = plans[m]
 		plan.generate_probes(pdf, seed=seed, probe_offset=lo)
 		plan.run(rtol)
-		q = plan.quadrature(fun, **fun_kwargs)
-		plan.close()
+		return plan.quadrature(fun, **fun_kwargs)
+
+	try:
+		if converge is not None:
+			return sharded_hutch(evaluate, converge=converge, batch=batch, group=group, full=full, **(converge_kwargs or {}))
+		assert nprobes is not None, "a fixed budget needs nprobes"
+		lo, hi = shard_range(nprobes, rank, world)
+		q = evaluate(lo, hi) if hi > lo else np.zeros(0)
+	finally:
+		for pl in plans.values():
+			pl.close()
 	if world == 1:
 		return merge_statistics(local_statistics(q))
 	return allreduce_trace(q, group=group)
@@ -162,7 +216,7 @@ def allgather_columns(src, ncols: int, dst, group=None):
 
 	world = dist.get_world_size(group)
 	if dist.get_backend(group) == "nccl":
-		dev = f"cuda:{src.ctx.device if src.ctx.device >= 0 else torch.cuda.current_device()}"
+		dev = f"cuda:{src.ctx.device}"  # the Context's own (resolved) ordinal, not torch's current device
 		tin = torch.as_tensor(src.cuda_array(0, ncols), device=dev)
 		tout = torch.as_tensor(dst.cuda_array(0, ncols * world), device=dev)
 		src.ctx.synchronize()  # libslq writes on its own stream

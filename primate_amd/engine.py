@@ -49,7 +49,9 @@ class Context:
 		h = C.c_void_p()
 		check(L.slq_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
 		self._h = h
-		self.device = device
+		d = C.c_int(-1)
+		check(L.slq_context_device(h, C.byref(d)))
+		self.device = int(d.value)  # the resolved ordinal: what owns every pointer and stream this context hands out
 
 	def synchronize(self):
 		check(_capi.lib().slq_context_synchronize(self._h))
@@ -431,8 +433,11 @@ class DiagAccumulator:
 class _CudaArrayView:
 	"""Flat fp64 device array described by the CUDA array interface (v2); keeps its owner alive."""
 
-	def __init__(self, dptr: int, count: int, owner, shape=None, dtype=np.float64):
+	def __init__(self, dptr: int, count: int, owner, shape=None, dtype=np.float64, device: Optional[int] = None):
 		self._owner = owner
+		## the GPU that owns the memory (the owner's Context); consumers must not assume torch's current device
+		ctx = getattr(owner, "ctx", None)
+		self.device_index = int(device) if device is not None else (int(ctx.device) if ctx is not None else None)
 		self.__cuda_array_interface__ = {
 			"shape": tuple(int(v) for v in shape) if shape is not None else (int(count),),
 			"typestr": "<f8" if np.dtype(dtype) == np.float64 else "<f4", "data": (int(dptr), False), "version": 2,

@@ -224,21 +224,37 @@ class TorchOperator(LinearOperator):
 	the device Lanczos loop on libslq's stream without a host round trip (`slq_device_callback_create`): the
 	GPU-native form of the reference's `LinearOperator` plugin surface (src/primate/operators.py:15-33)."""
 
-	def __init__(self, fn: Callable, n: int, dtype=np.float64):
+	def __init__(self, fn: Callable, n: int, dtype=np.float64, device: Optional[int] = None):
 		self.fn, self.shape, self.dtype = fn, (int(n), int(n)), np.dtype(dtype)
+		## the GPU `fn` computes on: LOCAL_RANK under torchrun (what `engine.Context` picks too), else torch's current
+		## device at construction time. The device products below do NOT consult torch.cuda.current_device().
+		self.device = device
+
+	def _device(self):
+		import os
+
+		import torch
+
+		if self.device is None:
+			self.device = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
+		return torch.device("cuda", int(self.device))
 
 	def matmat_device(self, X, Y, stream) -> None:
 		import torch
 
-		dev = torch.device("cuda", torch.cuda.current_device())
-		with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+		## X, Y and the stream belong to the GPU of the DeviceOperator's Context, which the views carry
+		owner = getattr(X, "device_index", None)
+		dev = torch.device("cuda", int(owner)) if owner is not None else self._device()
+		if self.device is not None and owner is not None:
+			assert int(self.device) == int(owner), f"TorchOperator on cuda:{self.device} driven by a Context on cuda:{owner}"
+		with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
 			x, y = torch.as_tensor(X, device=dev), torch.as_tensor(Y, device=dev)  # (b, n) views of column-major n x b
 			y.copy_(self.fn(x.T).T)
 
 	def _matmat(self, X: np.ndarray) -> np.ndarray:
 		import torch
 
-		dev = torch.device("cuda", torch.cuda.current_device())
+		dev = self._device()
 		return self.fn(torch.as_tensor(np.ascontiguousarray(X), device=dev).to(torch.float64 if self.dtype == np.float64 else torch.float32)).cpu().numpy()
 
 	def _matvec(self, x: np.ndarray) -> np.ndarray:

@@ -3,7 +3,7 @@
 # HBM-traffic PMC passes (each counter in its own pass, with --kernel-trace only, per the pool's rules).
 # usage: bash scripts/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...
 set -eo pipefail
-TAG=${1:-r01d}
+TAG=${1:-r02a}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -14,15 +14,20 @@ python3 $B > $OUT/bench_default_line.json
 python3 $B --orth 0 --no-cpu-baseline > $OUT/bench_orth0_line.json
 python3 $B --orth 30 --no-cpu-baseline --steps 4 > $OUT/bench_orth30_line.json
 python3 $B --workload lap3d_100 --no-cpu-baseline > $OUT/bench_lap3d_100_line.json
+python3 $B --workload lap3d_100 --orth 0 --no-cpu-baseline > $OUT/bench_lap3d_100_orth0_line.json
 for o in 3 0 30; do
   echo "== kernel stats orth $o"
-  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_orth$o -o run -- python3 $B --orth $o --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_orth${o}_line_under_rocprof.json
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_orth$o -o run -- python3 $B --orth $o --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench_orth${o}_line_under_rocprof.json
 done
-for cfg in "lap2d_1000 3" "lap2d_1000 0" "lap2d_1000 30" "lap3d_100 3"; do
+for o in 3 0; do
+  echo "== kernel stats lap3d_100 orth $o"
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_lap3d_100_orth$o -o run -- python3 $B --workload lap3d_100 --orth $o --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_lap3d_100_orth${o}_line_under_rocprof.json
+done
+for cfg in "lap2d_1000 3" "lap2d_1000 0" "lap2d_1000 30" "lap3d_100 3" "lap3d_100 0"; do
   set -- $cfg; w=$1; o=$2
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $c $w orth $o"
-    rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_${w}_orth$o -o run -- python3 $B --workload $w --orth $o --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
+    rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_${w}_orth$o -o run -- python3 $B --workload $w --orth $o --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null
   done
 done
 python3 $ROOT/scripts/summarise_pmc.py $OUT > $OUT/pmc_summary.json

@@ -6,12 +6,25 @@ traffic is known exactly: k_gen_probes writes one panel sweep, the ||v||^2 sweep
 
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+from pathlib import Path
 
 out_dir = sys.argv[1]
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def kernel_sources_sha256():
+	"""Same digest as bench.py:kernel_sources_sha256 - the bench line quotes a traffic figure only when it matches."""
+	h = hashlib.sha256()
+	for f in ("primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq.hip"):
+		h.update((ROOT / f).read_bytes())
+	return h.hexdigest()
+
 
 
 def classify(name: str, orth: int):
@@ -28,8 +41,9 @@ def classify(name: str, orth: int):
 	return None
 
 
-summary = {}
-for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 30), ("lap3d_100", 3)):
+summary = {"_meta": {"tag": os.path.basename(os.path.normpath(out_dir)), "kernel_sha256": kernel_sources_sha256(),
+                     "collected_by": "scripts/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)"}}
+for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 30), ("lap3d_100", 3), ("lap3d_100", 0)):
 	per = defaultdict(lambda: defaultdict(list))
 	names = {}
 	for counter in ("FETCH_SIZE", "WRITE_SIZE"):

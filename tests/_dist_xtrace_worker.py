@@ -16,10 +16,18 @@ def main():
 	import torch.distributed as dist
 
 	backend, out = sys.argv[1], sys.argv[2]
-	dist.init_process_group(backend)
-	rank, world = dist.get_rank(), dist.get_world_size()
 	if os.environ.get("DIST_TEST_SHARE_GPU0"):
 		os.environ["LOCAL_RANK"] = "0"  # rehearsal on a 1-GPU box: every rank on device 0
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	if backend == "nccl":
+		## one GPU per rank, bound BEFORE any GPU call: RCCL's communicator and barrier then use this rank's own device
+		import torch
+
+		torch.cuda.set_device(local_rank)
+		dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+	else:
+		dist.init_process_group(backend)
+	rank, world = dist.get_rank(), dist.get_world_size()
 	from conftest import laplacian_2d
 	from primate_amd.distributed import allgather_columns, sharded_diag_device, sharded_hutch_device, sharded_xtrace
 	from primate_amd.engine import DeviceMatrix
@@ -34,6 +42,10 @@ def main():
 	## probe-sharded hutch and diag on the same operator: one reduction each
 	cnt, mean, var = sharded_hutch_device(M._op, 45, 20, 3, fun="exp", seed=13, t=-0.5)
 	res["hutch"] = [int(cnt), float(mean), float(var)]
+	## adaptive stopping, batch-synchronous over the ranks (global batches of 12 probes)
+	e, info = sharded_hutch_device(M._op, None, 20, 3, fun="exp", seed=13, converge="confidence", batch=12, full=True,
+								   converge_kwargs=dict(confidence=0.95, atol=0.0, rtol=0.02), t=-0.5)  # fmt: skip
+	res["adaptive"] = [float(e), int(info.nit)]
 	est, numer, denom, c = sharded_diag_device(M._op, 35, 20, 3, fun="exp", seed=13, batch=8, t=-0.5)
 	res["diag"] = [int(c), float(np.sum(est)), float(np.sum(numer)), float(np.sum(denom))]
 	## the collective itself, on known data

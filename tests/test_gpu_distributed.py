@@ -49,6 +49,12 @@ def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
 		assert r["hutch"][0] == cnt == 45 and r["hutch"][1] == pytest.approx(mean, rel=1e-12) and r["hutch"][2] == pytest.approx(var, rel=1e-9)
 		assert r["diag"][0] == c == 35 and r["diag"][3] == pytest.approx(float(np.sum(denom)), rel=1e-13)
 		assert r["diag"][2] == pytest.approx(float(np.sum(numer)), rel=1e-10) and r["diag"][1] == pytest.approx(float(np.sum(est)), rel=1e-10)
+	## adaptive stopping: same stopping batch and (to rounding: narrower panels per rank) the same estimate as one process
+	e1, i1 = sharded_hutch_device(M._op, None, 20, 3, fun="exp", seed=13, converge="confidence", batch=12, full=True,
+								  converge_kwargs=dict(confidence=0.95, atol=0.0, rtol=0.02), t=-0.5)  # fmt: skip
+	assert 12 <= i1.nit < 600 and i1.nit % 12 == 0
+	for r in res:
+		assert r["adaptive"][1] == i1.nit and r["adaptive"][0] == pytest.approx(e1, rel=1e-11)
 	## shards of 10 columns run in a narrower panel geometry than the single 20-column batch: rounding only
 	assert res[0]["estimate"] == pytest.approx(single, rel=1e-9)
 	exact = np.sum(np.exp(-0.5 * np.linalg.eigvalsh(L.toarray())))
@@ -58,3 +64,22 @@ def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
 def test_rccl_allgather_code_path_world_of_one(tmp_path):
 	res = _launch(1, "nccl", tmp_path / "n1", 29532, share_gpu0=False)
 	assert res[0]["gather_ok"] and res[0]["nit"] == 50
+
+
+def test_rccl_two_ranks_two_gpus(tmp_path):
+	"""The RCCL path with a world larger than one: one GPU per rank, `all_gather_into_tensor` straight on the libslq
+	device buffers, ragged column shards. Needs two GPUs: skipped on the one-GPU box (the multi-rank RCCL path is
+	otherwise exercised only by the driver's multi-GPU bench; DESIGN.md §7 says so)."""
+	import torch
+
+	if torch.cuda.device_count() < 2:
+		pytest.skip("needs two GPUs")
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import xtrace
+
+	L = laplacian_2d(40)
+	M = MatrixFunction(L, fun="exp", deg=20, orth=3, t=-0.5)
+	single = xtrace(M, batch=20, pdf="sphere", seed=7, count=50, device_rng=True)
+	res = _launch(2, "nccl", tmp_path / "n2", 29535, share_gpu0=False)
+	assert all(r["gather_ok"] and r["nit"] == 50 for r in res)
+	assert len({r["estimate"] for r in res}) == 1 and res[0]["estimate"] == pytest.approx(single, rel=1e-9)

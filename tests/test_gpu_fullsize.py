@@ -84,6 +84,69 @@ def test_config3_estrada_index_full_size(eng):
 	np.testing.assert_allclose(Y1, W @ V, rtol=1e-9, atol=1e-9)  # A v is in the Krylov space: exact
 
 
+def test_config3_xtrace_as_worded_full_size(eng):
+	"""configs[2] as BASELINE.json words it: xtrace of exp(A) on the G(5e5, 16/n) graph, k = 40, 512 sample
+	vectors in batches of 128, device-drawn. The estimate lies within 3 sigma of a hutch estimate with the same
+	budget, and the column-sharded driver with a world of one (every f(A)-product goes through its shard
+	bookkeeping) returns the same number as the plain call."""
+	from primate_amd.distributed import sharded_xtrace
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch, xtrace
+
+	n, k = 500000, 40
+	rng = np.random.default_rng(1234)
+	mm = int(n * 16 / 2)
+	i, j = rng.integers(0, n, mm), rng.integers(0, n, mm)
+	keep = i != j
+	W = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(n, n)).tocsr()
+	W = ((W + W.T) > 0).astype(np.float64).tocsr()
+	W.sort_indices()
+	M = MatrixFunction(W, fun="exp", deg=k, orth=3)
+	est, info = xtrace(M, batch=128, count=512, seed=1234, device_rng=True, full=True)
+	h, hinfo = hutch(M, pdf="device:rademacher", converge="count", count=512, seed=1234, batch=256, full=True)
+	sigma = np.sqrt(float(np.ravel(hinfo.estimator._cov.covariance(ddof=1))[0]) / len(hinfo.estimator))  # standard error of the hutch mean
+	assert abs(est - h) < 3 * sigma, (est, h, sigma)
+	assert abs(est / 8.0589e7 - 1) < 5e-3  # round-1 measurement of this operator (DESIGN.md §5.3): 8.0589e7
+	assert sharded_xtrace(M, count=512, batch=128, seed=1234, device_rng=True) == est  # no process group: the plain call
+	## a world of one through the shard path: every f(A)-product is cut, "gathered" and copied back by the bookkeeping
+	## the multi-rank driver uses (the all-gather itself degenerates to a device copy)
+	same = xtrace(M, batch=128, count=512, seed=1234, device_rng=True, _shard=(0, 1, lambda src, ncols, dst: dst.copy_from(0, src, 0, ncols)))
+	np.testing.assert_allclose(same, est, rtol=1e-12)
+
+
+def test_config1_dense_spd_5000_on_the_matrix_cores(oracle, eng):
+	"""configs[0] on the HIP path: dense SPD 5000 x 5000 (fp64 MFMA operator), Rademacher probes, k = 20. 64 and 128
+	probes cover the 64-column launch and the two-halves launch of the fused three-term epilogue, 20 the 32-column
+	one; four columns of each batch are checked against the oracle on the same probes, orth 0 and 3."""
+	from primate_amd.operators import MatrixFunction
+	from primate_amd.trace import hutch
+
+	n, k = 5000, 20
+	rng = np.random.default_rng(1234)
+	B = rng.standard_normal((n, n))
+	A = B @ B.T / n + np.eye(n)
+	A = np.asfortranarray((A + A.T) / 2)
+	op = eng.DeviceOperator(A)
+	for P in (64, 128, 20):
+		V = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1)
+		cols = [0, 1, P // 2, P - 1]
+		for orth in (0, 3):
+			for fun in ("identity", "log"):
+				got = eng.quad_batch(op, V, k, orth, fun=fun)
+				ref = oracle.quad_batch(A, V[:, cols], k, orth, fun=fun, fresh_q=True)
+				np.testing.assert_allclose(got[cols], ref, rtol=1e-10, err_msg=f"P={P} orth={orth} {fun}")
+			## f = identity: the Gauss rule reproduces v^T A v exactly, every column
+			np.testing.assert_allclose(eng.quad_batch(op, V, k, orth, fun="identity"), np.einsum("ij,ij->j", V, A @ V), rtol=1e-11)
+	## the configs[0] call itself, on the device: hutch with 64 Rademacher probes, f = identity
+	M = MatrixFunction(A, fun="identity", deg=k, orth=3)
+	est, info = hutch(M, pdf="rademacher", converge="count", count=64, seed=1234, full=True)
+	from primate_amd.random import isotropic
+
+	V = isotropic(pdf="rademacher", seed=1234)(size=(n, 64))
+	np.testing.assert_allclose(est, np.mean(np.einsum("ij,ij->j", V, A @ V)), rtol=1e-11)
+	assert abs(est - np.trace(A)) < 6 * np.std(np.einsum("ij,ij->j", V, A @ V), ddof=1) / 8
+
+
 def eng_quad_identity(plan, op, P, k, orth):
 	"""f = identity: sum theta*tau*||v||^2 = v^T A v (exact for any k >= 1)."""
 	return plan.quadrature("identity")

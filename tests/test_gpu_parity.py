@@ -215,6 +215,12 @@ def test_operator_products(eng):
 	assert PyOp.calls == 21
 	A32 = A.astype(np.float32)
 	np.testing.assert_allclose(eng.DeviceOperator(A32).matmat(X.astype(np.float32)), ref, rtol=2e-5, atol=2e-5)
+	## a dense operator's product is A X for WHATEVER is given (eigen_operators.h:24-30), also a non-symmetric array, on
+	## the fp64 matrix-core kernel and on the fp32 column-walking one
+	G = rng.standard_normal((301, 301))
+	Xg = np.asfortranarray(rng.standard_normal((301, 21)))
+	np.testing.assert_allclose(eng.DeviceOperator(G).matmat(Xg), G @ Xg, rtol=1e-11, atol=1e-11)
+	np.testing.assert_allclose(eng.DeviceOperator(G.astype(np.float32)).matmat(Xg.astype(np.float32)), G @ Xg, rtol=3e-4, atol=3e-4)
 
 
 def test_all_three_operator_kinds_agree_on_slq(oracle, eng):
@@ -369,8 +375,9 @@ def test_device_probe_generator(eng):
 	assert not np.array_equal(p1.get_probes()[:, 100:150], p2.get_probes())
 
 
-def test_full_size_properties_c2(eng):
-	"""BASELINE configs[1] at full size, 256 device probes: size-independent checks."""
+def test_full_size_properties_c2(eng, oracle):
+	"""BASELINE configs[1] at full size, 256 device probes in the production geometry (2 panels of 128): the
+	oracle on four of the columns (first and last of each panel), then size-independent checks."""
 	L2 = laplacian_2d(1000)
 	op = eng.DeviceOperator(L2)
 	n = L2.shape[0]
@@ -396,8 +403,13 @@ def test_full_size_properties_c2(eng):
 	## probes are bitwise the same; the block partition of the reductions depends on the panel count,
 	## so the values agree to rounding, not bitwise)
 	plan.generate_probes("rademacher", seed=1234)
+	V = plan.get_probes()  # the device-drawn probes, n x 256
 	plan.run()
 	q_all = plan.quadrature("log")
+	cols = [0, 127, 128, 255]
+	ref = oracle.quad_batch(L2, np.asfortranarray(V[:, cols]), 30, 3, fun="log", fresh_q=True)
+	np.testing.assert_allclose(q_all[cols], ref, rtol=1e-10)
+	del V
 	half = eng.LanczosPlan(op, 128, 30, 3)
 	parts = []
 	for off in (0, 128):

@@ -203,6 +203,47 @@ def test_sharded_reduce_world2_gloo(tmp_path):
 	assert all("OK" in o for o in outs), outs
 
 
+_GLOO_ADAPTIVE_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from primate_amd.distributed import sharded_hutch
+from primate_amd.trace import hutch
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+vals = np.random.default_rng(7).standard_normal(4096) * 3.0 + 50.0   # per-probe values by GLOBAL probe id
+
+class Fake:   # what hutch needs of an operator with device-drawn probes
+	shape, dtype = (64, 64), np.dtype(np.float64)
+	def matvec(self, x): return x
+	def quad_generated(self, m, pdf, seed, offset): return vals[offset:offset + m]
+
+ok = True
+for conv, kw in (("confidence", dict(confidence=0.95, atol=0.4, rtol=0.0)), ("default", {}), ("count", dict(count=70)), ("tolerance", dict(atol=0.0, rtol=2e-3))):
+	ref, rinfo = hutch(Fake(), pdf="device:rademacher", converge=conv, batch=24, seed=1, full=True, **kw)
+	got, ginfo = sharded_hutch(lambda lo, hi: vals[lo:hi], converge=conv, batch=24, full=True, **kw)
+	same = (got == ref and ginfo.nit == rinfo.nit and ginfo.message == rinfo.message)
+	print("RANK", rank, conv, "nit", ginfo.nit, rinfo.nit, got, ref, "same" if same else "DIFFERENT")
+	ok = ok and same and ginfo.nit % 24 == 0 and ginfo.nit < 4096
+print("RANK", rank, "OK" if ok else "FAIL")
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+def test_sharded_adaptive_stopping_world2_gloo(tmp_path):
+	"""SURVEY.md §8(e) "Early stopping": the batch-synchronous sharded hutch stops at the same batch, with the same
+	estimate and message, as the single-process hutch(full=True) on the same per-probe values, for every criterion."""
+	script = tmp_path / "worker_adaptive.py"
+	script.write_text(_GLOO_ADAPTIVE_WORKER)
+	env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", WORLD_SIZE="2")
+	procs = [subprocess.Popen([sys.executable, str(script), str(ROOT)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+	outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+	assert all(p.returncode == 0 for p in procs), outs
+	assert all("OK" in o for o in outs), outs
+
+
 def test_toeplitz_plugin_operator_on_the_host():
 	"""The FFT-applied Toeplitz plugin equals the dense Toeplitz product (symmetric and non-symmetric)."""
 	from scipy.linalg import toeplitz
