@@ -62,14 +62,19 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 FUSED_MAX_R = 8  # slq_kernels.hpp:kFusedMaxR
 
 
-def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True):
 	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each
 	vector panel a kernel touches is read or written once, the CSR arrays once per panel of `pw`
-	probes. Two launch sequences exist per Lanczos step (slq.hip:slq_plan_run):
-	  fused (CSR, r_j <= 4): the SpMM is recomputed in each pass and only the last pass writes —
-	    alpha pass [spmm_3term], dots pass [reorth_dot], update pass [reorth_update | axpy_norm];
-	  store-and-revisit (deeper reorthogonalisation): spmm_3term writes w, then reorth_dot /
+	probes. Launch sequences per Lanczos step (slq.hip:enqueue_run; `LanczosPlan.describe()["sequence"]`):
+	  "fused" (CSR with gather locality, r_j <= 8): the SpMM is recomputed in each pass and only the last pass writes —
+	    alpha pass [spmm_3term] at r = 0, merged alpha+dots pass [reorth_dot] at r >= 1, update pass
+	    [reorth_update | axpy_norm];
+	  "fused_stored_u" (CSR without gather locality, 1 <= r_j <= 8): the merged pass also stores u and the update pass
+	    reads it back instead of gathering again; its r = 0 steps run the sweeps;
+	  "sweeps" (deeper reorthogonalisation, other operators): spmm_3term writes w, then reorth_dot /
 	    reorth_update (or axpy_norm) revisit it in place."""
+	if sequence is None:
+		sequence = "fused" if fused else "sweeps"
 	npan = math.ceil(b / pw)
 	vec = s * n * b
 	csr = npan * ((s + 4) * nnz + 4 * (n + 1))
@@ -79,12 +84,13 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
 	launches["axpy_norm"] += 1
 	for j in range(deg):
 		r = 0 if orth == 0 else min(j + 1, orth)
-		if fused and r <= FUSED_MAX_R:
-			rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
+		rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
+		if sequence == "fused" and r <= FUSED_MAX_R:
 			if r == 0:
 				# alpha pass (orth = 0 only; with r >= 1 alpha comes out of the dots pass): q_c only (q_c.q_p comes
-				# from the previous update pass's cross term), over the upper triangle of the symmetric CSR
-				out["spmm_3term"] += npan * ((s + 4) * (nnz + n) // 2 + 4 * (n + 1)) + vec
+				# from the previous update pass's cross term), over the upper triangle of an exactly symmetric CSR
+				nz = (nnz + n) // 2 if upper_alpha else nnz
+				out["spmm_3term"] += npan * ((s + 4) * nz + 4 * (n + 1)) + vec
 				launches["spmm_3term"] += 1
 			if r > 0:
 				out["reorth_dot"] += csr + rd * vec
@@ -92,6 +98,12 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True):
 			k = "reorth_update" if r > 0 else "axpy_norm"
 			out[k] += csr + (rd + 1) * vec
 			launches[k] += 1
+			continue
+		if sequence == "fused_stored_u" and 1 <= r <= FUSED_MAX_R:
+			out["reorth_dot"] += csr + (rd + 1) * vec  # gathers, reads the ring rows, WRITES u
+			launches["reorth_dot"] += 1
+			out["reorth_update"] += (rd + 2) * vec  # reads u and the ring rows, writes w; no gather
+			launches["reorth_update"] += 1
 			continue
 		out["spmm_3term"] += csr + (2 if j == 0 else 3) * vec  # gather q_c, read q_p, write w
 		launches["spmm_3term"] += 1
@@ -208,10 +220,9 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	ms_per_step = elapsed / steps * 1e3
 
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
-	vlen = 16 // s  # probes per lane (16-byte loads)
-	pw = next(l * vlen for l in (8, 16, 32, 64) if l * vlen >= P or l == 64)
-	fused = os.environ.get("SLQ_FUSED", "1") != "0"
-	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, fused=fused)
+	info = plan.describe()  # panel geometry and launch sequence the library chose
+	pw, fused = info["panel_width"], info["sequence"] != "sweeps"
+	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]))
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)
 	launches = prof[dom]["launches"]
@@ -246,7 +257,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 		"config": {
 			"workload": f"{'configs[1]: logdet via SLQ' if workload == 'lap2d_1000' and dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={fun}",
 			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
-			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused),
+			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused), "plan": info,
 			"kernel_events_in_timed_region": bool(profiled),
 		},
 		"trace_estimates_per_s": round(world * P * steps / elapsed, 1),

@@ -142,6 +142,19 @@ int slq_plan_destroy(slq_plan *plan);
 int slq_plan_workspace_bytes(const slq_plan *plan, size_t *bytes);
 int slq_plan_query_bytes(int dtype, int64_t n, int nprobes, int deg, int orth, int keep_basis,
                          size_t *bytes);
+/* What the plan decided (panel geometry and launch sequence): for byte models and records. */
+typedef struct {
+  int panel_width;   /* PW: probes per panel row                                                        */
+  int panels;        /* NP                                                                              */
+  int ring_slots;    /* S                                                                               */
+  int sequence;      /* steps with r_j <= 8: 0 store-and-revisit sweeps, 1 fused recompute passes,      */
+                     /* 2 fused passes with the intermediate stored (operators without gather locality) */
+  int pipelined;     /* dots/update passes use the pipelined row loop                                   */
+  int reordered;     /* rows stored in the XCD-aware reverse Cuthill-McKee order                        */
+  int upper_alpha;   /* alpha pass walks the upper triangle (exactly symmetric CSR)                     */
+  double far_per_row;/* stored nonzeros per row further than 4096 rows from the diagonal                */
+} slq_plan_info;
+int slq_plan_describe(const slq_plan *plan, slq_plan_info *out);
 
 /* Parity mode: host probes, column-major n x nprobes of the plan's dtype (ld >= n). */
 int slq_plan_set_probes(slq_plan *plan, const void *X, int64_t ldx);

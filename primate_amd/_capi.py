@@ -61,6 +61,7 @@ _SIGNATURES = {
 	"slq_plan_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _PP]),
 	"slq_plan_destroy": (C.c_int, [_P]),
 	"slq_plan_workspace_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+	"slq_plan_describe": (C.c_int, [_P, C.c_void_p]),
 	"slq_plan_query_bytes": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
 	"slq_plan_set_probes": (C.c_int, [_P, _P, C.c_int64]),
 	"slq_plan_generate_probes": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_uint64]),
@@ -99,6 +100,13 @@ _SIGNATURES = {
 	"slq_lanczos_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_size_t]),
 }  # fmt: skip
 DEVICE_MATMAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+class PlanInfo(C.Structure):
+	"""slq_plan_info (include/slq.h)."""
+
+	_fields_ = [("panel_width", C.c_int), ("panels", C.c_int), ("ring_slots", C.c_int), ("sequence", C.c_int), ("pipelined", C.c_int),
+				("reordered", C.c_int), ("upper_alpha", C.c_int), ("far_per_row", C.c_double)]  # fmt: skip
+
+
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 

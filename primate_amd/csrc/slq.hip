@@ -58,7 +58,21 @@ struct slq_context {
   hipStream_t stream;
   bool own_stream;
   int num_cus;
+  // Operators, plans, diag accumulators and device matrices hold the context they were created on. A context
+  // destroyed while such objects are alive (a garbage collector tears handles down in no particular order) only
+  // becomes unusable for NEW objects; its stream lives until the last dependant has been destroyed.
+  int refs = 0;
+  bool dead = false;
 };
+static void ctx_retain(slq_context *ctx) { ++ctx->refs; }
+static void ctx_free(slq_context *ctx) {
+  hipSetDevice(ctx->device);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+static void ctx_release(slq_context *ctx) {
+  if (--ctx->refs == 0 && ctx->dead) ctx_free(ctx);
+}
 
 enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2, OP_DEVICE_CALLBACK = 3 };
 
@@ -205,9 +219,8 @@ extern "C" int slq_context_create(int device, void *hip_stream, slq_context **ou
 
 extern "C" int slq_context_destroy(slq_context *ctx) {
   if (!ctx) return SLQ_OK;
-  hipSetDevice(ctx->device);
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-  delete ctx;
+  ctx->dead = true;
+  if (ctx->refs == 0) ctx_free(ctx);
   return SLQ_OK;
 }
 
@@ -457,8 +470,10 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     if (colind[p] < 0 || colind[p] >= n)
       return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[p], (long long)p);
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
   *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   const size_t es = esize(dtype);
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
@@ -634,8 +649,10 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
     return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices");
   if (!d_rowptr || (nnz > 0 && (!d_colind || !d_vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
   // The kernels read colind/vals up to kCsrPad entries past nnz (gather_row_uniform), which a caller's arrays do not
   // guarantee: the operator owns padded device-to-device copies (rowptr is copied too, so that the caller may free
   // all three). The arrays are NOT validated (they live on the device): indices must lie in [0, n).
@@ -665,8 +682,10 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
   SLQ_TRY(check_dtype(dtype));
   if (n <= 0 || n >= (int64_t)1 << 31 || !A || lda < n) return fail(SLQ_EINVAL, "bad dense operator shape");
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
   *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
   const size_t es = esize(dtype);
   // Y = A X for whatever is given (eigen_operators.h:24-30 does not ask for symmetry either). k_dense_mfma_3term reads
@@ -709,8 +728,10 @@ extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_m
   SLQ_TRY(check_dtype(dtype));
   if (n <= 0 || n >= (int64_t)1 << 31) return fail(SLQ_EINVAL, "bad operator shape");
   if (!fn) return fail(SLQ_EINVAL, "Supplied object is missing 'matvec' attribute.");
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
   *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr, RowTiles{}};
   *out = op;
   return SLQ_OK;
@@ -722,8 +743,10 @@ extern "C" int slq_device_callback_create(slq_context *ctx, int dtype, int64_t n
   *out = nullptr;
   SLQ_TRY(check_dtype(dtype));
   if (n <= 0 || n >= (int64_t)1 << 31) return fail(SLQ_EINVAL, "bad operator size");
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
   *op = slq_operator{ctx, OP_DEVICE_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, nullptr, user, nullptr, nullptr, RowTiles{}};
   op->dev_fn = fn;
   *out = op;
@@ -750,6 +773,7 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
     hipFree((void *)op->tiles.lidx);
     hipFree((void *)op->tiles.self_idx);
   }
+  ctx_release(op->ctx);
   delete op;
   return SLQ_OK;
 }
@@ -934,6 +958,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   if (p->part) hipFree(p->part);
   if (p->quad_d) hipFree(p->quad_d);
   if (p->st.active) hipFree(p->st.active);
+  ctx_release(p->ctx);
   delete p;
   return SLQ_OK;
 }
@@ -948,9 +973,11 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   if (nprobes <= 0) return fail(SLQ_EINVAL, "nprobes must be positive");
   SLQ_TRY(normalise_params(op->n, &deg, &orth));
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_plan *p = new (std::nothrow) slq_plan();
   if (!p) return fail(SLQ_ENOMEM, "host allocation failed");
   p->ctx = ctx;
+  ctx_retain(ctx);
   p->op = op;
   p->dtype = op->dtype;
   p->n = (int)op->n;
@@ -1187,6 +1214,27 @@ static int set_kernel_attributes(slq_plan *p) {
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return SLQ_OK;
+}
+
+// which launch sequence the steps with r <= kFusedMaxR take (enqueue_run): 0 sweeps, 1 recompute passes, 2 stored u
+static int plan_sequence(const slq_plan *p) {
+  const slq_operator *op = p->op;
+  if (op->kind != OP_CSR || p->sw.fused == 0 || p->sw.mgs || p->nstale > 0) return 0;
+  if (p->sw.fused == 2 || op->far_per_row <= 4.0) return 1;
+  return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !p->sw.tiles) ? 2 : 0;
+}
+
+extern "C" int slq_plan_describe(const slq_plan *p, slq_plan_info *out) {
+  if (!p || !out) return fail(SLQ_EINVAL, "plan/out is NULL");
+  out->panel_width = p->PW;
+  out->panels = p->NP;
+  out->ring_slots = p->S;
+  out->sequence = plan_sequence(p);
+  out->pipelined = p->pipelined ? 1 : 0;
+  out->reordered = p->op->perm_d ? 1 : 0;
+  out->upper_alpha = p->op->rowptr_u ? 1 : 0;
+  out->far_per_row = p->op->far_per_row;
   return SLQ_OK;
 }
 
@@ -1835,7 +1883,8 @@ extern "C" int slq_diag_create(slq_context *ctx, int64_t n, slq_diag **out) {
   d->ctx = ctx; d->n = n; d->count = 0; d->buf = nullptr; d->op = nullptr;
   hipError_t e = hipMalloc((void **)&d->buf, (size_t)3 * n * 8);
   if (e == hipSuccess) e = hipMemsetAsync(d->buf, 0, (size_t)3 * n * 8, ctx->stream);
-  if (e != hipSuccess) { delete d; return fail(SLQ_ENOMEM, "diag accumulators: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { delete d; /* not yet retained */ return fail(SLQ_ENOMEM, "diag accumulators: %s", hipGetErrorString(e)); }
+  ctx_retain(ctx);
   *out = d;
   return SLQ_OK;
 }
@@ -1844,6 +1893,7 @@ extern "C" int slq_diag_destroy(slq_diag *d) {
   if (!d) return SLQ_OK;
   hipSetDevice(d->ctx->device);
   if (d->buf) hipFree(d->buf);
+  ctx_release(d->ctx);
   delete d;
   return SLQ_OK;
 }
@@ -1913,6 +1963,7 @@ extern "C" int slq_dmat_create(slq_context *ctx, int64_t n, int cols, slq_dmat *
   hipError_t e = hipMalloc((void **)&m->d, (size_t)n * cols * 8);
   if (e == hipSuccess) e = hipMemsetAsync(m->d, 0, (size_t)n * cols * 8, ctx->stream);
   if (e != hipSuccess) { delete m; return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "dmat: %s", hipGetErrorString(e)); }
+  ctx_retain(ctx);
   *out = m;
   return SLQ_OK;
 }
@@ -1922,6 +1973,7 @@ extern "C" int slq_dmat_destroy(slq_dmat *m) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
   if (m->d) hipFree(m->d);
+  ctx_release(m->ctx);
   delete m;
   return SLQ_OK;
 }

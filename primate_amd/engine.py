@@ -203,6 +203,14 @@ class LanczosPlan:
 		check(_capi.lib().slq_plan_workspace_bytes(self._h, C.byref(b)))
 		return b.value
 
+	def describe(self) -> dict:
+		"""Panel geometry and launch sequence the library chose for this plan (slq_plan_describe)."""
+		info = _capi.PlanInfo()
+		check(_capi.lib().slq_plan_describe(self._h, C.byref(info)))
+		d = {k: getattr(info, k) for k, _ in _capi.PlanInfo._fields_}
+		d["sequence"] = {0: "sweeps", 1: "fused", 2: "fused_stored_u"}[d["sequence"]]
+		return d
+
 	def set_probes(self, X: np.ndarray):
 		X = np.asarray(X)
 		X = X.reshape(-1, 1) if X.ndim == 1 else X
