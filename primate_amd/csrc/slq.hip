@@ -117,12 +117,13 @@ struct Switches {
   int cross;       // SLQ_CROSS     q_c.q_p from the update pass's cross term
   int tiles;       // SLQ_TILES     experimental LDS row tiles
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
+  int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
   int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, pipe, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, dense_tile16, pipe, fused_pad, spmm_pad})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -162,6 +163,7 @@ struct slq_plan {
   unsigned graph_variant;
   Switches sw;
   bool pipelined;             // dots/update passes run the pipelined row loop (slq_plan_create)
+  int dense_ks;               // dense MFMA operator with big tiles: K split over this many workgroups per row tile (0: 16-row kernel)
 };
 
 static int env_int(const char *name, int dflt) {
@@ -993,7 +995,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_PIPE", -1),
+                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1),
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   // Row loop of the dots/update passes (slq_kernels.hpp: k_csr_pass). Measured on configs[1] and on the 100^3 grid
   // (DESIGN.md §5.3): rows of up to 5 nonzeros are fastest with the plain loop at 2 resident workgroups per CU (82.9
@@ -1042,13 +1044,28 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->st.active, bp * 2 * sizeof(int) + 16);
   if (e == hipSuccess) e = hipMalloc((void **)&p->quad_d, (bp + 2 * bp * (size_t)deg) * 8);
-  if (e == hipSuccess && op->kind != OP_CSR) e = hipMalloc(&p->T, (size_t)p->slot_stride * p->esz);
+  // dense fp64 operator on the matrix cores with 32-row tiles: n/32 workgroups per panel rarely fill 256 CUs, so K is
+  // also split over dense_ks workgroups whose raw products land in dense_ks slabs behind T. ks minimises the number
+  // of workgroup rounds times the work per workgroup, plus a small cost per slab.
+  p->dense_ks = 0;  // 0: the 16-row kernel with its fused epilogue
+  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma && p->PW >= 32 && !p->sw.dense_tile16) {
+    const int rw = 32 * (kWaves / (p->PW >= 64 ? 2 : 1));
+    const double wgs = (double)((p->n + rw - 1) / rw) * p->NP;
+    double best = 1e30;
+    const int forced = env_int("SLQ_DENSE_KSPLIT", 0);
+    for (int ks = 1; ks <= 16; ++ks) {
+      const double cost = std::ceil(wgs * ks / ctx->num_cus) / ks + 0.005 * ks;
+      if ((forced > 0 && ks == forced) || (forced <= 0 && cost < best - 1e-12)) { best = cost; p->dense_ks = ks; }
+    }
+  }
+  const size_t t_slabs = op->kind == OP_CSR ? 0 : (size_t)(1 + p->dense_ks);
+  if (e == hipSuccess && t_slabs) e = hipMalloc(&p->T, t_slabs * (size_t)p->slot_stride * p->esz);
   if (e != hipSuccess) {
     slq_plan_destroy(p);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP,
                 "plan workspace (%zu bytes of Lanczos panels): %s", ring_bytes, hipGetErrorString(e));
   }
-  p->bytes = ring_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + (p->T ? (size_t)p->slot_stride * p->esz : 0);
+  p->bytes = ring_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + t_slabs * (size_t)p->slot_stride * p->esz;
   double *s = p->scal;
   p->st.alpha = s; s += (size_t)(deg + 1) * bp;
   s += (size_t)orth * bp;  // nu rows for t = -orth .. -1 (zero unless the drop-in entry preloads stale columns)
@@ -1214,6 +1231,7 @@ static int set_kernel_attributes(slq_plan *p) {
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
   return SLQ_OK;
 }
 
@@ -1365,9 +1383,31 @@ extern "C" int slq_plan_get_probes(slq_plan *p, void *X, int64_t ldx) {
 static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *Wn, int first, int plain, int *nblk_out) {
   const slq_operator *op = p->op;
   hipStream_t st = p->ctx->stream;
+  // panels of 32+ columns: big tiles, K split over workgroups, epilogue by k_3term_slabs (k_dense_mfma_tile);
+  // 16-column panels: the 16-row kernel with its fused epilogue. SLQ_DENSE_TILE16=1 forces the latter (A/B runs).
+  if (p->dense_ks > 0) {
+    const int ks = p->dense_ks;
+    double *raw = (double *)p->T + p->slot_stride;  // slabs 1..ks of T (slab 0 is the unfused product)
+    const int ncg = p->PW >= 64 ? 2 : 1;
+    const int rw = 32 * (kWaves / ncg);
+    const dim3 g((p->n + rw - 1) / rw, p->NP, ks);
+    for (int col0 = 0; col0 < p->PW; col0 += 32 * ncg) {  // PW = 128: two 64-column halves, A streamed twice
+      if (ncg == 2)
+        k_dense_mfma_tile<2><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc, p->PW, col0, raw, p->slot_stride);
+      else
+        k_dense_mfma_tile<1><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc, p->PW, col0, raw, p->slot_stride);
+    }
+    // second stage: sum the slabs in slab order, three-term epilogue and alpha partials (or the plain product)
+    const dim3 gS(p->nblkS, p->NP);
+    DISPATCH(SLQ_F64, p->LPR,
+             (k_3term_slabs<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n, (const F *)raw, ks, p->slot_stride, (const F *)Wc, (const F *)Wp, (F *)Wn,
+                                                             p->st.coefA, p->part, p->bpad, first, plain)));
+    if (nblk_out) *nblk_out = p->nblkS;
+    return SLQ_OK;
+  }
+  const size_t part_rows = (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT);
   const int nblk = (p->n + 15) / 16;
-  if ((size_t)nblk > (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT))
-    return fail(SLQ_EINVAL, "dense operator too large for the partials buffer");
+  if ((size_t)nblk > part_rows) return fail(SLQ_EINVAL, "dense operator too large for the partials buffer");
   const dim3 g(nblk, p->NP);
 #define DENSE_LAUNCH(TWV, COL0)                                                                             \
   {                                                                                                         \
@@ -1376,7 +1416,7 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
                                                         (const double *)Wp, (double *)Wn, p->st.coefA, p->part, p->bpad, first, plain, p->PW, COL0); \
   }
   switch (p->PW) {
-    case 128: DENSE_LAUNCH(64, 0) DENSE_LAUNCH(64, 64) break;  // two 64-column halves: A streamed twice, LDS 64 KiB
+    case 128: DENSE_LAUNCH(64, 0) DENSE_LAUNCH(64, 64) break;
     case 64: DENSE_LAUNCH(64, 0) break;
     case 32: DENSE_LAUNCH(32, 0) break;
     default: DENSE_LAUNCH(16, 0) break;

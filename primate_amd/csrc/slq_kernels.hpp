@@ -830,6 +830,103 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_3term(
   }
 }
 
+// ---- the same product for panels of 32+ columns: big workgroup tiles, wide loads, K split over workgroups ----------
+// k_dense_mfma_3term above re-reads the whole probe panel for every 16 output rows (n/16 workgroups x n x TW x 8 B:
+// 4x the bytes of A at TW = 64) with one 8-byte load per fragment element and nothing in flight while the matrix
+// cores work: 0.196 ms per 5000^2 x 64 product, 1.0 TB/s on A, bound by what a CU's vector-memory pipe can have
+// in flight. Here:
+//  * a WAVE owns 32 output rows x 32 columns (2 x 2 accumulator tiles). The assignment of matrix rows / columns to
+//    MFMA fragment indices is free, so both are INTERLEAVED: fragment row m of row tile rt is matrix row
+//    rbase + 2m + rt, fragment column c of column tile h is matrix column cbase + 2c + h. A lane then fetches both
+//    row tiles' A elements with ONE 16-byte load (rows 2m, 2m+1 of one k are adjacent in the column-major A) and both
+//    column tiles' panel elements with one 16-byte load: 2 loads of 1 KiB feed 4 MFMAs;
+//  * a WORKGROUP is (8 / NCG) row groups x NCG column groups of such waves (128 x 64 or 256 x 32): the waves of a row
+//    group issue the same A loads, those of a column group the same panel loads, at the same time - the CU's L1
+//    serves the repeats, so per k-quad the CU pulls 4 + 2 KiB from L2 for 32 MFMAs;
+//  * the fragments of quad q + kDensePrefetch are requested when quad q's MFMAs issue (register ring): A streams
+//    from HBM / the Infinity Cache, 1-2 us away;
+//  * n/128 row tiles do not fill 256 CUs, so K is split over gridDim.z workgroups; every workgroup writes its raw
+//    partial product to slab z and k_3term_slabs sums the slabs in slab order and applies the three-term epilogue
+//    (bitwise reproducible; the slabs are a few MB).
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+#ifndef SLQ_DENSE_PREFETCH
+#define SLQ_DENSE_PREFETCH 6
+#endif
+constexpr int kDensePrefetch = SLQ_DENSE_PREFETCH;
+
+template <int NCG>
+__global__ __launch_bounds__(kBlock) void k_dense_mfma_tile(int n, const double *__restrict__ A, int64_t lda,
+                                                            const double *__restrict__ X, int ldw, int col0,
+                                                            double *__restrict__ raw, int64_t raw_stride) {
+  constexpr int RG = kWaves / NCG;  // row groups of 32 rows per workgroup
+  const int PW = ldw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int rg = wave / NCG, cg = wave % NCG;
+  const int panel = blockIdx.y;
+  const int rbase = (blockIdx.x * RG + rg) * 32;
+  const int cbase = col0 + 32 * cg;
+  const int64_t poff = (int64_t)panel * n * PW;
+  const double *xw = X + poff + cbase + 2 * lr;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[rt][h] = (d4_t)0.0;
+  const int kq_all = (n + 3) / 4;  // k-quads, split over the gridDim.z workgroups of this row tile
+  const int ks = gridDim.z, kz = blockIdx.z;
+  const int perz = (kq_all + ks - 1) / ks;
+  const int q_begin = min(kq_all, kz * perz), q_end = min(kq_all, q_begin + perz);
+  const int rowA = rbase + 2 * lr;  // this lane's two rows: rowA (row tile 0), rowA + 1 (row tile 1)
+  const bool pair_ok = rowA + 1 < n, one_ok = rowA < n;
+  auto loadA = [&](int q) -> d2u_t {
+    const int k = q * 4 + lk;
+    d2u_t a = (d2u_t)0.0;
+    if (q < q_end && k < n) {
+      const double *ap = A + (int64_t)k * lda + rowA;
+      if (pair_ok) a = *(const d2u_t *)ap;
+      else if (one_ok) a[0] = ap[0];
+    }
+    return a;
+  };
+  auto loadX = [&](int q) -> d2u_t {
+    const int k = q * 4 + lk;
+    d2u_t b = (d2u_t)0.0;
+    if (q < q_end && k < n) b = *(const d2u_t *)(xw + (int64_t)k * PW);
+    return b;
+  };
+  constexpr int D = kDensePrefetch;
+  d2u_t ar[D], br[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    ar[i] = loadA(q_begin + i);
+    br[i] = loadX(q_begin + i);
+  }
+  for (int q0 = q_begin; q0 < q_end; q0 += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const d2u_t a = ar[i], b = br[i];
+      ar[i] = loadA(q0 + i + D);  // refill the slot; quads past the range contribute zeros
+      br[i] = loadX(q0 + i + D);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        acc[0][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[h], acc[0][h], 0, 0, 0);
+        acc[1][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[h], acc[1][h], 0, 0, 0);
+      }
+    }
+  }
+  double *out = raw + (int64_t)kz * raw_stride + poff;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + 2 * (lk + 4 * r) + rt;
+        if (row < n) out[(int64_t)row * PW + cbase + 2 * lr + h] = acc[rt][h][r];
+      }
+}
+
 // Three-term epilogue for operators whose product is computed by a separate kernel (dense,
 // host callback): in: T = A (Wc) unscaled. w = sc*T - cp*Wp ; partA += (sc*Wc) * w ; Wn = w.
 template <typename F, int LPR>
@@ -864,6 +961,47 @@ __global__ __launch_bounds__(kBlock) void k_3term(int n, const F *T, const F *Wc
     }
   }
   block_reduce_columns<F, LPR>(aacc, red, partA + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// The same epilogue over a product that arrives as `nslab` partial slabs (K split over workgroups, k_dense_mfma32):
+// T = sum of the slabs in slab order; plain != 0: Wn = T only.
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_3term_slabs(int n, const F *T, int nslab, int64_t slab_stride, const F *Wc, const F *Wp,
+                                                        F *Wn, const double *__restrict__ coefA, double *__restrict__ partA,
+                                                        int bpad, int first, int plain) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int colbase = panel * PW + cl * V;
+  VF sc = (VF)(F)1, cp = (VF)(F)0;
+  if (!plain) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sc[v] = (F)coefA[colbase + v];
+      cp[v] = (F)coefA[bpad + colbase + v];
+    }
+  }
+  VF aacc = (VF)(F)0;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int r0 = (blockIdx.x * kWaves + wave) * RPW; r0 < n; r0 += stride) {
+    const int row = r0 + g;
+    if (row < n) {
+      const int64_t ro = poff + (int64_t)row * PW;
+      VF t = *(const VF *)(T + ro);
+      for (int z = 1; z < nslab; ++z) t += *(const VF *)(T + (int64_t)z * slab_stride + ro);
+      VF w = sc * t;
+      if (!plain) {
+        if (!first) w -= cp * *(const VF *)(Wp + ro);
+        aacc += (sc * *(const VF *)(Wc + ro)) * w;
+      }
+      *(VF *)(Wn + ro) = w;
+    }
+  }
+  if (!plain) block_reduce_columns<F, LPR>(aacc, red, partA + (int64_t)blockIdx.x * bpad + panel * PW);
 }
 
 // ---- sweep B (orth = 0): w -= cB * Wc ; partN += w^2 --------------------------------------------
