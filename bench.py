@@ -107,15 +107,19 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 			continue
 		out["spmm_3term"] += csr + (2 if j == 0 else 3) * vec  # gather q_c, read q_p, write w
 		launches["spmm_3term"] += 1
+		## "sweeps_ring32" (SLQ_RING32 opt-in): ring columns i >= 2 are read from the fp32 archive (half the bytes), and
+		## the last update sweep also writes w there
+		half = sequence == "sweeps_ring32"
+		cols = lambda a, b: sum(0.5 if (half and i >= 2) else 1.0 for i in range(a, b))  # noqa: E731
 		if r == 0:
 			out["axpy_norm"] += 3 * vec  # read w, q_c; write w
 			launches["axpy_norm"] += 1
 		else:
 			for i0 in range(0, r, chunk):
 				rc = min(chunk, r - i0)
-				out["reorth_dot"] += (rc + (2 if i0 == 0 else 1)) * vec
+				out["reorth_dot"] += (cols(i0, i0 + rc) + (2 if i0 == 0 else 1)) * vec
 				launches["reorth_dot"] += 1
-			out["reorth_update"] += (r + 2) * vec
+			out["reorth_update"] += (cols(0, r) + 2 + (0.5 if half else 0.0)) * vec
 			launches["reorth_update"] += 1
 	return out, launches
 

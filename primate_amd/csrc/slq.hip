@@ -119,11 +119,12 @@ struct Switches {
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
+  int ring32;      // SLQ_RING32    opt-in: finished Lanczos vectors archived as fp32 for deep reorthogonalisation
   int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, dense_tile16, pipe, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -163,6 +164,9 @@ struct slq_plan {
   unsigned graph_variant;
   Switches sw;
   bool pipelined;             // dots/update passes run the pipelined row loop (slq_plan_create)
+  float *ring32;              // fp32 archive ring (ring32_on): slot t % S32 holds vector t as floats, same panel layout
+  int S32;
+  bool ring32_on;
   int dense_ks;               // dense MFMA operator with big tiles: K split over this many workgroups per row tile (0: 16-row kernel)
 };
 
@@ -954,6 +958,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   for (auto &ev : p->pool) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
   if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);
   if (p->ring) hipFree(p->ring);
+  if (p->ring32) hipFree(p->ring32);
   if (p->T) hipFree(p->T);
   if (p->stage) hipFree(p->stage);
   if (p->scal) hipFree(p->scal);
@@ -988,15 +993,26 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->orth = orth;
   p->keep_basis = keep_basis != 0;
   p->esz = esize(op->dtype);
+  p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
+                   env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
+                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
   p->S = ring_slots(deg, orth, p->keep_basis);
+  // Opt-in fp32 archive (SLQ_RING32=1; fp64 plans with reorthogonalisation deeper than the fused passes reach, basis
+  // not kept): the fp64 ring shrinks to the three live vectors and every finished vector is also stored as fp32;
+  // reorthogonalisation columns i >= 2 are read from the archive and accumulated in fp64. Changes results at the
+  // 1e-8 level of the Lanczos coefficients, hence never the default.
+  p->ring32 = nullptr;
+  p->S32 = 0;
   p->slot_stride = (int64_t)p->NP * p->n * p->PW;
+  p->ring32_on = p->sw.ring32 && op->dtype == SLQ_F64 && !p->keep_basis && orth > kFusedMaxR;
+  if (p->ring32_on) {
+    p->S = 3;
+    p->S32 = orth + 1;
+  }
   p->rmax = std::max(p->keep_basis ? deg : orth, 1);
-  p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
-                   env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1),
-                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   // Row loop of the dots/update passes (slq_kernels.hpp: k_csr_pass). Measured on configs[1] and on the 100^3 grid
   // (DESIGN.md §5.3): rows of up to 5 nonzeros are fastest with the plain loop at 2 resident workgroups per CU (82.9
   // against 91.7 ms per step), 7-point rows with the pipelined loop at ONE resident workgroup per CU (93.7 against
@@ -1040,6 +1056,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + 1 + (size_t)p->rmax) * bp;
   const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
+  const size_t ring32_bytes = p->ring32_on ? (size_t)p->S32 * (size_t)p->slot_stride * sizeof(float) : 0;
+  if (e == hipSuccess && p->ring32_on) e = hipMalloc((void **)&p->ring32, ring32_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->st.active, bp * 2 * sizeof(int) + 16);
@@ -1065,7 +1083,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP,
                 "plan workspace (%zu bytes of Lanczos panels): %s", ring_bytes, hipGetErrorString(e));
   }
-  p->bytes = ring_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + t_slabs * (size_t)p->slot_stride * p->esz;
+  p->bytes = ring_bytes + ring32_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + t_slabs * (size_t)p->slot_stride * p->esz;
   double *s = p->scal;
   p->st.alpha = s; s += (size_t)(deg + 1) * bp;
   s += (size_t)orth * bp;  // nu rows for t = -orth .. -1 (zero unless the drop-in entry preloads stale columns)
@@ -1107,7 +1125,9 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 // Kernels that may be launched with more than the default 64 KiB of dynamic LDS (gamma staging):
 // raise their limit once, outside any stream capture.
 template <typename F, int L> static hipError_t raise_lds_limits() {
-  hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if constexpr (std::is_same<F, double>::value)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_reorth_update<F, L, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // fused passes: LDS padding caps their residency (SLQ_ALPHA_LDS_PAD experiments; dots/update: 2 per CU)
   std::vector<const void *> fused_fns = {
       (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0, 0>,
@@ -1238,6 +1258,7 @@ static int set_kernel_attributes(slq_plan *p) {
 // which launch sequence the steps with r <= kFusedMaxR take (enqueue_run): 0 sweeps, 1 recompute passes, 2 stored u
 static int plan_sequence(const slq_plan *p) {
   const slq_operator *op = p->op;
+  if (p->ring32_on) return 3;
   if (op->kind != OP_CSR || p->sw.fused == 0 || p->sw.mgs || p->nstale > 0) return 0;
   if (p->sw.fused == 2 || op->far_per_row <= 4.0) return 1;
   return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !p->sw.tiles) ? 2 : 0;
@@ -1290,6 +1311,14 @@ static int init_from_probes(slq_plan *p, int sphere) {
   PROFILED(p, SLQ_K_FINALIZE,
            hipLaunchKernelGGL(k_fin_init, dim3((p->bpad + 63) / 64), dim3(kFinThreads), 0, st, p->st, p->part,
                               p->nblkS, sphere, (double)p->n));
+  if (p->ring32_on) {  // vector 0 joins the fp32 archive
+    switch (p->LPR) {
+      case 64: k_archive32<64><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), p->ring32); break;
+      case 32: k_archive32<32><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), p->ring32); break;
+      case 16: k_archive32<16><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), p->ring32); break;
+      default: k_archive32<8><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), p->ring32); break;
+    }
+  }
   HIP_TRY(hipGetLastError());
   p->probes_ready = true;
   p->ran = false;
@@ -1499,6 +1528,31 @@ static int quadrature_lanes(int deg) {
   return std::max(1, std::min(64, lanes));
 }
 
+// one dots sweep of the store-and-revisit sequence, with or without the fp32 archive
+template <typename F, int L> static inline void launch_reorth_dot(slq_plan *p, dim3 gS, hipStream_t st, int j, int i0, int rc) {
+  if constexpr (std::is_same<F, double>::value) {
+    if (p->ring32_on) {
+      k_reorth_dot<F, L, 1><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB,
+                                                        p->part, p->bpad, p->ring32, p->slot_stride, p->S32);
+      return;
+    }
+  }
+  k_reorth_dot<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB,
+                                                    p->part, p->bpad, (const float *)nullptr, 0, 1);
+}
+template <typename F, int L>
+static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds, hipStream_t st, int j, int i0, int rc, int archive) {
+  if constexpr (std::is_same<F, double>::value) {
+    if (p->ring32_on) {
+      k_reorth_update<F, L, 1><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
+                                                            p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, p->ring32, p->slot_stride, p->S32, archive);
+      return;
+    }
+  }
+  k_reorth_update<F, L, 0><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
+                                                        p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, (float *)nullptr, 0, 1, 0);
+}
+
 // one fused CSR pass; the pipelined row loop exists for one-row-per-wave panels (L == 64) and not for the alpha pass
 template <typename F, int L, int PASS, int LP, int RC, typename... Args>
 static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStream_t st, Args... args) {
@@ -1513,7 +1567,8 @@ static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStrea
 
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
 static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
-  const bool fused = fused_mode != 0;
+  if (p->ring32_on && p->nstale > 0) return fail(SLQ_EINVAL, "SLQ_RING32 does not combine with preloaded stale ring columns");
+  const bool fused = fused_mode != 0 && !p->ring32_on;  // the fused passes do not feed the fp32 archive
   hipStream_t st = p->ctx->stream;
   const int bp = p->bpad, deg = p->deg, S = p->S;
   const double eps = p->dtype == SLQ_F64 ? std::numeric_limits<double>::epsilon()
@@ -1676,9 +1731,9 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       for (int i = 0; i < r; ++i) {
         PROFILED(p, SLQ_K_REORTH_DOT,
                  DISPATCH(p->dtype, p->LPR,
-                          (k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                          (k_reorth_dot<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n,
                                               (F *)p->ring, p->slot_stride, S, j, i, 1, (int)(i == 0),
-                                              p->st.coefB, p->part, bp))));
+                                              p->st.coefB, p->part, bp, (const float *)nullptr, 0, 1))));
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, 1), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i, orth_tol));
@@ -1689,9 +1744,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
         const int rc = std::min(kReorthChunk, r - i0);
         PROFILED(p, SLQ_K_REORTH_DOT,
                  DISPATCH(p->dtype, p->LPR,
-                          (k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
-                                              (F *)p->ring, p->slot_stride, S, j, i0, rc, (int)(i0 == 0),
-                                              p->st.coefB, p->part, bp))));
+                          (launch_reorth_dot<F, L>(p, gS, st, j, i0, rc))));
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i0, orth_tol));
@@ -1850,9 +1903,7 @@ static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r) {
     const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
     PROFILED(p, SLQ_K_REORTH_UPD,
              DISPATCH(p->dtype, p->LPR,
-                      (k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(
-                          p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
-                          p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad))));
+                      (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r)))));  // last chunk: w is final
   }
   return SLQ_OK;
 }

@@ -1049,12 +1049,32 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
 // orthogonalisation pass after the three-term step), r_chunk <= kReorthChunk columns per launch
 // so the accumulators stay in registers.
 // ring: base of slot 0; vector t lives in slot t % S; slot stride = NP*n*PW elements.
-template <typename F, int LPR>
+// A32 (opt-in, fp64 only: SLQ_RING32): the fp64 ring holds only the three live vectors (slots t % 3) and
+// every finished vector is also kept as fp32 in an archive ring (slot t % S32); reorthogonalisation columns
+// i >= 2 (vectors j-2 and older) are read from the archive - half the bytes - and accumulated in fp64.
+template <typename F, int LPR, int A32>
+__device__ __forceinline__ typename VecT<F>::type ring_column(const F *U0, int64_t slot_stride, int S, const float *R32,
+                                                              int64_t stride32, int S32, int64_t poff32, int t, int gi, int64_t ro) {
+  using VF = typename VecT<F>::type;
+  if (A32 && gi >= 2) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t x = *(const f2_t *)(R32 + (int64_t)ring_slot(t, S32) * stride32 + poff32 + ro);
+    VF v;
+    v[0] = (F)x[0];
+    v[1] = (F)x[1];
+    return v;
+  }
+  return *(const VF *)(U0 + (int64_t)ring_slot(t, S) * slot_stride + ro);
+}
+
+template <typename F, int LPR, int A32>
 __global__ __launch_bounds__(kBlock) void k_reorth_dot(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int rc, int apply_axpy,
-    const double *__restrict__ coefB, double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad) {
+    const double *__restrict__ coefB, double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad,
+    const float *__restrict__ ring32, int64_t stride32, int S32) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
+  static_assert(!A32 || V == 2, "the fp32 archive exists for fp64 plans only");
   __shared__ double red[kWaves * 64 * V];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
@@ -1083,7 +1103,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
     VF u[kReorthChunk];
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
-      if (i < rc) u[i] = *(const VF *)(U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride + ro);
+      if (i < rc) u[i] = ring_column<F, LPR, A32>(U0, slot_stride, S, ring32, stride32, S32, poff, j - i0 - i, i0 + i, ro);
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
       if (i < rc) dacc[i] += u[i] * w;
@@ -1099,11 +1119,11 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
 // ---- sweep C: w -= sum_i gamma_i * W_{t_i} ; partN += w^2 ----------------------------------------
 // gamma[i][col] (coefficient on the UNNORMALISED ring vector; zero where the reference's skip
 // thresholds apply, lanczos.h:62) is staged in LDS once per block: r * PW doubles.
-template <typename F, int LPR>
+template <typename F, int LPR, int A32>
 __global__ __launch_bounds__(kBlock) void k_reorth_update(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int r,
     const double *__restrict__ gamma /* [r][bpad], already offset to column i0 */,
-    double *__restrict__ partN, int bpad) {
+    double *__restrict__ partN, int bpad, float *ring32, int64_t stride32, int S32, int archive /* also store w as fp32 */) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   constexpr int UR = SLQ_UPD_UR;
@@ -1119,6 +1139,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
   __syncthreads();
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
+  float *W32 = A32 ? ring32 + (int64_t)ring_slot(j + 1, S32) * stride32 + poff : nullptr;
   VF nacc = (VF)(F)0;
   // UR CONSECUTIVE row groups per wave and iteration (one contiguous UR*RPW*PW*sizeof(F) block):
   // the gamma read from LDS is amortised over UR rows and UR loads per column are in flight.
@@ -1133,11 +1154,10 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       w[u] = *(const VF *)(W + ro[u]);
     }
     for (int i = 0; i < r; ++i) {
-      const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
       const VF gm = *(const VF *)(gl + i * PW + cl * V);
       VF x[UR];
 #pragma unroll
-      for (int u = 0; u < UR; ++u) x[u] = *(const VF *)(U + ro[u]);
+      for (int u = 0; u < UR; ++u) x[u] = ring_column<F, LPR, A32>(U0, slot_stride, S, ring32, stride32, S32, poff, j - i0 - i, i0 + i, ro[u]);
 #pragma unroll
       for (int u = 0; u < UR; ++u) w[u] -= gm * x[u];
     }
@@ -1146,11 +1166,37 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       const int row = r0 + u * RPW;
       if (row < n) {
         *(VF *)(W + ro[u]) = w[u];
+        if (A32 && archive) {
+          typedef float f2_t __attribute__((ext_vector_type(2)));
+          f2_t y;
+          y[0] = (float)w[u][0];
+          y[1] = (float)w[u][V - 1];
+          *(f2_t *)(W32 + ro[u]) = y;
+        }
         nacc += w[u] * w[u];
       }
     }
   }
   block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// fp64 panel slot -> fp32 archive slot (the probes, vector 0 of a run)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_archive32(int n, const double *__restrict__ W, float *__restrict__ W32) {
+  constexpr int PW = Geo<double, LPR>::PW, RPW = Geo<double, LPR>::RPW;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LPR, cl = lane % LPR;
+  const int64_t poff = (int64_t)blockIdx.y * n * PW + cl * 2;
+  const int stride = gridDim.x * kWaves * RPW;
+  for (int row = (blockIdx.x * kWaves + wave) * RPW + g; row < n; row += stride) {
+    const d2_t x = *(const d2_t *)(W + poff + (int64_t)row * PW);
+    f2_t y;
+    y[0] = (float)x[0];
+    y[1] = (float)x[1];
+    *(f2_t *)(W32 + poff + (int64_t)row * PW) = y;
+  }
 }
 
 // ---- per-step scalar kernels ("finalize"): partials -> alpha / beta / next coefficients ---------

@@ -586,6 +586,33 @@ def test_non_local_operator_uses_stored_u_passes(oracle, eng, monkeypatch):
 				monkeypatch.delenv(k)
 
 
+def test_opt_in_fp32_archive_ring(oracle, eng, monkeypatch):
+	"""SLQ_RING32=1 (opt-in): finished Lanczos vectors archived as fp32, reorthogonalisation columns j-2 and older read
+	from the archive. Not bit-compatible by construction; the bar here is 1e-7 relative per probe against the oracle
+	(the north_star's is 1e-6; measured worst case 2e-9, profiles/r02_ring32_eval.json). Only plans with reorthogonalisation
+	deeper than 8 columns and no kept basis take the path."""
+	A = random_spd_graph(3000, 6.0, seed=21)
+	rng = np.random.default_rng(4)
+	X = np.asfortranarray(rng.standard_normal((3000, 70)))
+	op = eng.DeviceOperator(A)
+	monkeypatch.setenv("SLQ_RING32", "1")
+	for deg, orth in ((40, 12), (40, 40)):
+		plan = eng.LanczosPlan(op, 70, deg, orth)
+		assert plan.describe()["sequence"] == "sweeps_ring32" and plan.describe()["ring_slots"] == 3
+		plan.set_probes(X)
+		plan.run()
+		got = plan.quadrature("log")
+		a, b, steps = plan.tridiag()
+		assert np.all(steps == deg)
+		plan.close()
+		ref = oracle.quad_batch(A, X, deg, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(got, ref, rtol=1e-7)
+	assert eng.LanczosPlan(op, 70, 40, 3).describe()["sequence"] != "sweeps_ring32"  # shallow reorthogonalisation: untouched
+	assert eng.LanczosPlan(op, 8, 40, 40, keep_basis=True).describe()["sequence"] != "sweeps_ring32"  # kept basis: untouched
+	monkeypatch.delenv("SLQ_RING32")
+	assert eng.LanczosPlan(op, 70, 40, 40).describe()["sequence"] != "sweeps_ring32"
+
+
 def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 	"""SLQ_TILES=1: the experimental LDS-staged fused passes (k_csr_pass_tiled) give the generic
 	passes' results to rounding, for both tile heights and with/without reorthogonalisation."""
