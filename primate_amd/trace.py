@@ -47,6 +47,11 @@ def hutch(
 	    column draws (reference tests/test_random.py:23-39) — evaluated in one device run, and fed to
 	    the estimator one by one, stopping at the same sample the reference would stop at;
 	  * with `full`/`callback`, whole batches are drawn and folded at once (trace.py:104-110).
+	One observable difference follows from the first point: the estimate and the stopping sample are the reference's, but
+	a caller-supplied `np.random.Generator` is left further along its stream than the reference leaves it - up to
+	`batch` - 1 probes (max(batch, 256) - 1 for a MatrixFunction under a count criterion) drawn past the stopping sample
+	are discarded (and, for composite criteria, evaluated for nothing). Code that keeps drawing from the same generator
+	after `hutch` returns sees different numbers than with the reference; pass a seed, or a generator of its own.
 	"""
 	f_dtype = is_valid_operator(A)
 	N: int = A.shape[0]

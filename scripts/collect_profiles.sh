@@ -30,6 +30,8 @@ for cfg in "lap2d_1000 3" "lap2d_1000 0" "lap2d_1000 30" "lap3d_100 3" "lap3d_10
     rocprofv3 --output-format csv --kernel-trace --pmc $c -d $OUT/pmc_${c}_${w}_orth$o -o run -- python3 $B --workload $w --orth $o --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null
   done
 done
+echo "== kernel stats dense (configs[0] operator: 5000^2, 64 / 128 probes)"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_dense -o run -- python3 $ROOT/scripts/bench_dense.py > $OUT/bench_dense.log 2>&1
 python3 $ROOT/scripts/summarise_pmc.py $OUT > $OUT/pmc_summary.json
 find $OUT -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $f)); cp $f $OUT/${d}_kernel_stats.csv 2>/dev/null || true; done
 # the raw traces are large: keep summaries only
