@@ -88,7 +88,7 @@ struct slq_operator {
   void *user;
   int32_t *perm_d;               // device: stored row i = caller row perm[i]; null if not reordered
   std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
-  RowTiles tiles;                // LDS row tiles for the wide-panel fused passes (tile_ptr == null: none)
+  TileMeta tiles;                // workgroup LDS tiles of the fused passes (tile_ptr == null: none; SLQ_TILES)
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
@@ -169,6 +169,8 @@ struct slq_plan {
   bool ring32_on;
   int dense_ks;               // dense MFMA operator with big tiles: K split over this many workgroups per row tile (0: 16-row kernel)
 };
+
+constexpr double kTileMaxColsPerRow = 4.0;  // tiles are kept when a tile row needs at most this many distinct panel rows
 
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
@@ -368,54 +370,112 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
 }
 
 
-// Row tiles for k_csr_pass_tiled: per tile of TR consecutive rows (one wave's unit of work), the sorted
-// list of distinct columns (plus the rows themselves) and, per nonzero, its position in that list.
-// Built once on the host from the (possibly reordered) CSR arrays. Returns false if even TR = 2 needs
-// more than `cap` distinct panel rows per tile (irregular / random sparsity: no reuse, generic path).
-static bool build_row_tiles(int64_t n, const int32_t *rowptr, const int32_t *colind, int cap, int *TR_out,
-                            std::vector<int32_t> &tile_ptr, std::vector<int32_t> &tile_cols,
-                            std::vector<uint16_t> &lidx, std::vector<uint16_t> &self_idx, int *tiles_per_xcd,
-                            int *max_cols) {
-  const int forced = env_int("SLQ_TILE_ROWS", 0);
-  for (int TR : {4, 2}) {
-    if (forced && TR != forced) continue;
-    const int64_t ntiles_real = (n + TR - 1) / TR;
-    const int tpx = (int)((ntiles_real + 7) / 8);
-    const int64_t ntiles = (int64_t)tpx * 8;
-    tile_ptr.assign((size_t)ntiles + 1, 0);
-    tile_cols.clear();
-    lidx.assign((size_t)rowptr[n], 0);
-    self_idx.assign((size_t)n, 0);
-    std::vector<int32_t> u;
-    int mx = 0;
-    bool ok = true;
-    for (int64_t t = 0; t < ntiles && ok; ++t) {
-      const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
-      u.clear();
-      for (int64_t r = r0; r < r1; ++r) {
-        u.push_back((int32_t)r);
-        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) u.push_back(colind[p]);
+// Workgroup tiles for k_csr_tile_pass (SLQ_TILES). The rows of every XCD chunk are regrouped into compact clusters:
+// seeds are taken in the chunk's current order (natural or Cuthill-McKee), a cluster grows breadth-first by the
+// unassigned in-chunk neighbour with the most links into it (ties: first discovered), up to kTileRows rows and as long
+// as its rows and columns together stay within kTileCols distinct indices. Clusters follow one another in seed order,
+// so the sweep of the chunk keeps its locality. order_in: stored row -> caller row; inv_in: caller row -> stored row
+// (null: identity). order_out: the new stored order; tile_row: first stored row of every tile; xcd_tile: tile range of
+// every chunk. Returns false when a single row already needs more than kTileCols indices (no tiling for this operator).
+static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *colind, const int32_t *order_in, const int32_t *inv_in,
+                           std::vector<int32_t> &order_out, std::vector<int32_t> &tile_row, int32_t xcd_tile[9]) {
+  const int64_t chunk = (n + 7) / 8;
+  const int tmax = std::max(1, std::min(env_int("SLQ_TILE_ROWS", kTileRows), 64));
+  const int dcap = std::max(8, std::min(env_int("SLQ_TILE_COLS", kTileCols), kTileCols));
+  std::vector<char> assigned((size_t)n, 0);
+  std::vector<int32_t> stamp((size_t)n, -1);
+  struct Cand { int32_t node, cnt, disc; };
+  std::vector<Cand> cand;
+  order_out.clear();
+  order_out.reserve((size_t)n);
+  tile_row.assign(1, 0);
+  int32_t cid = 0;
+  for (int x = 0; x < 8; ++x) {
+    xcd_tile[x] = (int32_t)tile_row.size() - 1;
+    const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    auto in_chunk = [&](int32_t v) {
+      const int64_t b = inv_in ? inv_in[v] : v;
+      return b >= lo && b < hi;
+    };
+    for (int64_t b = lo; b < hi; ++b) {
+      const int32_t seed = order_in ? order_in[b] : (int32_t)b;
+      if (assigned[(size_t)seed]) continue;
+      int D = 0, ndisc = 0;
+      cand.clear();
+      const size_t first_member = order_out.size();
+      auto new_cols = [&](int32_t v) {
+        int c = stamp[(size_t)v] != cid;
+        for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) c += (stamp[(size_t)colind[p]] != cid && colind[p] != v);
+        return c;
+      };
+      auto add = [&](int32_t v) {
+        assigned[(size_t)v] = 1;
+        order_out.push_back(v);
+        if (stamp[(size_t)v] != cid) { stamp[(size_t)v] = cid; ++D; }
+        for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+          const int32_t c = colind[p];
+          if (stamp[(size_t)c] != cid) { stamp[(size_t)c] = cid; ++D; }
+          if (c != v && !assigned[(size_t)c] && in_chunk(c)) {
+            bool found = false;
+            for (auto &k : cand) if (k.node == c) { ++k.cnt; found = true; break; }
+            if (!found) cand.push_back(Cand{c, 1, ndisc++});
+          }
+        }
+      };
+      if (new_cols(seed) > dcap) return false;
+      add(seed);
+      while ((int)(order_out.size() - first_member) < tmax && !cand.empty()) {
+        size_t best = 0;
+        for (size_t q = 1; q < cand.size(); ++q)
+          if (cand[q].cnt > cand[best].cnt || (cand[q].cnt == cand[best].cnt && cand[q].disc < cand[best].disc)) best = q;
+        const int32_t v = cand[best].node;
+        cand[best] = cand.back();
+        cand.pop_back();
+        if (assigned[(size_t)v]) continue;
+        if (D + new_cols(v) > dcap) continue;  // would not fit the image: leave it for a later cluster
+        add(v);
       }
-      std::sort(u.begin(), u.end());
-      u.erase(std::unique(u.begin(), u.end()), u.end());
-      if ((int)u.size() > cap) { ok = false; break; }
-      mx = std::max(mx, (int)u.size());
-      for (int64_t r = r0; r < r1; ++r) {
-        self_idx[(size_t)r] = (uint16_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin());
-        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
-          lidx[(size_t)p] = (uint16_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin());
-      }
-      tile_cols.insert(tile_cols.end(), u.begin(), u.end());
-      tile_ptr[(size_t)t + 1] = (int32_t)tile_cols.size();
-    }
-    if (ok) {
-      *TR_out = TR;
-      *tiles_per_xcd = tpx;
-      *max_cols = mx;
-      return true;
+      tile_row.push_back((int32_t)order_out.size());
+      ++cid;
     }
   }
-  return false;
+  xcd_tile[8] = (int32_t)tile_row.size() - 1;
+  for (int x = 7; x >= 0; --x) xcd_tile[x] = std::min(xcd_tile[x], xcd_tile[x + 1]);
+  return (int64_t)order_out.size() == n;
+}
+
+// Tile lists of the STORED CSR: per tile the ascending distinct indices of its rows and their columns, per nonzero the
+// position of its column in that list, per row the position of the row itself.
+static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *colind, const std::vector<int32_t> &tile_row,
+                            std::vector<int32_t> &tile_ptr, std::vector<int32_t> &tile_cols, std::vector<int32_t> &lcol,
+                            std::vector<int32_t> &self_idx, int *max_cols) {
+  const size_t ntiles = tile_row.size() - 1;
+  tile_ptr.assign(ntiles + 1, 0);
+  tile_cols.clear();
+  lcol.assign((size_t)rowptr[n] + kCsrPad, 0);
+  self_idx.assign((size_t)n, 0);
+  std::vector<int32_t> u;
+  int mx = 0;
+  for (size_t t = 0; t < ntiles; ++t) {
+    const int64_t r0 = tile_row[t], r1 = tile_row[t + 1];
+    u.clear();
+    for (int64_t r = r0; r < r1; ++r) {
+      u.push_back((int32_t)r);
+      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) u.push_back(colind[p]);
+    }
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    mx = std::max(mx, (int)u.size());
+    for (int64_t r = r0; r < r1; ++r) {
+      self_idx[(size_t)r] = (int32_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin());
+      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
+        lcol[(size_t)p] = (int32_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin());
+    }
+    tile_cols.insert(tile_cols.end(), u.begin(), u.end());
+    tile_ptr[t + 1] = (int32_t)tile_cols.size();
+  }
+  tile_cols.insert(tile_cols.end(), kCsrPad, 0);
+  *max_cols = mx;
 }
 
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
@@ -480,7 +540,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   ctx_retain(ctx);
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
   const size_t es = esize(dtype);
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
   std::vector<int32_t> rp2, ci2;
@@ -532,6 +592,41 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
     }
   }
   if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
+  // SLQ_TILES (opt-in): regroup the rows into compact clusters = workgroup tiles of k_csr_tile_pass, on top of whatever
+  // order was chosen above. Kept only if the tiles actually share rows: on average at most kTileMaxColsPerRow distinct
+  // panel rows per tile row (a 7-point grid reaches 3.0, a 5-point grid 1.7; a random graph 10+ and keeps the generic path).
+  std::vector<int32_t> tile_row;
+  int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool have_tiles = false;
+  if (env_int("SLQ_TILES", 0) != 0 && nnz > 0 && n >= 4096) {
+    std::vector<int32_t> order, inv0;
+    if (op->perm_h) {
+      inv0.resize((size_t)n);
+      for (int64_t i = 0; i < n; ++i) inv0[(size_t)(*op->perm_h)[(size_t)i]] = (int32_t)i;
+    }
+    if (build_clusters(n, rowptr, colind, op->perm_h ? op->perm_h->data() : nullptr, op->perm_h ? inv0.data() : nullptr, order, tile_row, xcd_tile)) {
+      // distinct indices per tile row, estimated on the caller's numbering (exact lists are built below)
+      int64_t dsum = 0;
+      std::vector<int32_t> stamp((size_t)n, -1);
+      for (size_t t = 0; t + 1 < tile_row.size(); ++t)
+        for (int32_t q = tile_row[t]; q < tile_row[t + 1]; ++q) {
+          const int32_t v = order[(size_t)q];
+          if (stamp[(size_t)v] != (int32_t)t) { stamp[(size_t)v] = (int32_t)t; ++dsum; }
+          for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp)
+            if (stamp[(size_t)colind[pp]] != (int32_t)t) { stamp[(size_t)colind[pp]] = (int32_t)t; ++dsum; }
+        }
+      const double per_row = (double)dsum / (double)n;
+      if (env_int("SLQ_DEBUG", 0) != 0)
+        fprintf(stderr, "[slq] tiles: %zu clusters, %.2f rows each, %.2f distinct panel rows per row\n", tile_row.size() - 1,
+                (double)n / (double)(tile_row.size() - 1), per_row);
+      if (per_row <= kTileMaxColsPerRow) {
+        have_tiles = true;
+        if (!op->perm_h) op->perm_h = new (std::nothrow) std::vector<int32_t>();
+        if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+        op->perm_h->swap(order);
+      }
+    }
+  }
   if (op->perm_h) {
     std::vector<int32_t> &perm = *op->perm_h;
     std::vector<int32_t> inv((size_t)n);
@@ -614,31 +709,33 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
       }
     }
   }
-  // LDS row tiles (wide-panel fused passes). EXPERIMENTAL, off by default: measured 1.7x SLOWER than the
-  // generic passes on configs[1] (1.6 vs 0.93 ms for the alpha pass): the 1-KiB-row LDS
-  // images cap residency at 8 waves per CU. SLQ_TILES=1 enables it (kept tested).
-  if (env_int("SLQ_TILES", 0) != 0 && nnz > 0) {
-    std::vector<int32_t> tp, tc;
-    std::vector<uint16_t> li, si;
-    int TR = 0, tpx = 0, mx = 0;
-    const int cap = 16;  // distinct panel rows per wave-private tile (registers + 16 KiB of LDS per wave)
-    if (build_row_tiles(n, rowptr, colind, cap, &TR, tp, tc, li, si, &tpx, &mx)) {
-      int32_t *d_tp = nullptr, *d_tc = nullptr;
-      uint16_t *d_li = nullptr, *d_si = nullptr;
-      hipError_t te = hipMalloc((void **)&d_tp, tp.size() * 4);
-      if (te == hipSuccess) te = hipMalloc((void **)&d_tc, std::max<size_t>(tc.size(), 1) * 4);
-      if (te == hipSuccess) te = hipMalloc((void **)&d_li, std::max<size_t>(li.size(), 1) * 2);
-      if (te == hipSuccess) te = hipMalloc((void **)&d_si, si.size() * 2);
-      if (te == hipSuccess) te = hipMemcpyAsync(d_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-      if (te == hipSuccess) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-      if (te == hipSuccess) te = hipMemcpyAsync(d_li, li.data(), li.size() * 2, hipMemcpyHostToDevice, ctx->stream);
-      if (te == hipSuccess) te = hipMemcpyAsync(d_si, si.data(), si.size() * 2, hipMemcpyHostToDevice, ctx->stream);
-      if (te == hipSuccess) te = hipStreamSynchronize(ctx->stream);
-      op->tiles = RowTiles{d_tp, d_tc, d_li, d_si, TR, mx, tpx};
-      if (te != hipSuccess) {
-        slq_operator_destroy(op);
-        return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "row-tile upload: %s", hipGetErrorString(te));
-      }
+  // workgroup tiles (SLQ_TILES): lists of the stored CSR, uploaded next to it
+  if (have_tiles) {
+    std::vector<int32_t> tp, tc, lc, si;
+    int mx = 0;
+    build_tile_meta(n, rowptr, colind, tile_row, tp, tc, lc, si, &mx);
+    int32_t *d_tr = nullptr, *d_tp = nullptr, *d_tc = nullptr, *d_lc = nullptr, *d_si = nullptr;
+    hipError_t te = hipMalloc((void **)&d_tr, tile_row.size() * 4);
+    if (te == hipSuccess) te = hipMalloc((void **)&d_tp, tp.size() * 4);
+    if (te == hipSuccess) te = hipMalloc((void **)&d_tc, tc.size() * 4);
+    if (te == hipSuccess) te = hipMalloc((void **)&d_lc, lc.size() * 4);
+    if (te == hipSuccess) te = hipMalloc((void **)&d_si, si.size() * 4);
+    if (te == hipSuccess) te = hipMemcpyAsync(d_tr, tile_row.data(), tile_row.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess) te = hipMemcpyAsync(d_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess) te = hipMemcpyAsync(d_lc, lc.data(), lc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess) te = hipMemcpyAsync(d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess) te = hipStreamSynchronize(ctx->stream);
+    op->tiles.tile_row = d_tr;
+    op->tiles.tile_ptr = d_tp;
+    op->tiles.tile_cols = d_tc;
+    op->tiles.lcol = d_lc;
+    op->tiles.self_idx = d_si;
+    for (int x = 0; x < 9; ++x) op->tiles.xcd_tile[x] = xcd_tile[x];
+    op->tiles.max_cols = mx;
+    if (te != hipSuccess) {
+      slq_operator_destroy(op);
+      return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile upload: %s", hipGetErrorString(te));
     }
   }
   *out = op;
@@ -662,7 +759,7 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   // The kernels read colind/vals up to kCsrPad entries past nnz (gather_row_uniform), which a caller's arrays do not
   // guarantee: the operator owns padded device-to-device copies (rowptr is copied too, so that the caller may free
   // all three). The arrays are NOT validated (they live on the device): indices must lie in [0, n).
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
+  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
   const size_t es = esize(dtype);
   hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
@@ -692,7 +789,7 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   ctx_retain(ctx);
-  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr, RowTiles{}};
+  *op = slq_operator{ctx, OP_DENSE, dtype, n, n * n, nullptr, nullptr, nullptr, n, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
   const size_t es = esize(dtype);
   // Y = A X for whatever is given (eigen_operators.h:24-30 does not ask for symmetry either). k_dense_mfma_3term reads
   // A(row, k) and is right for any A; k_dense_panel walks row `row` of A as the contiguous COLUMN `row`, which is A^T:
@@ -738,7 +835,7 @@ extern "C" int slq_callback_create(slq_context *ctx, int dtype, int64_t n, slq_m
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   ctx_retain(ctx);
-  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr, RowTiles{}};
+  *op = slq_operator{ctx, OP_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, fn, user, nullptr, nullptr, TileMeta{}};
   *out = op;
   return SLQ_OK;
 }
@@ -753,7 +850,7 @@ extern "C" int slq_device_callback_create(slq_context *ctx, int dtype, int64_t n
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   ctx_retain(ctx);
-  *op = slq_operator{ctx, OP_DEVICE_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, nullptr, user, nullptr, nullptr, RowTiles{}};
+  *op = slq_operator{ctx, OP_DEVICE_CALLBACK, dtype, n, 0, nullptr, nullptr, nullptr, 0, false, nullptr, user, nullptr, nullptr, TileMeta{}};
   op->dev_fn = fn;
   *out = op;
   return SLQ_OK;
@@ -773,12 +870,11 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->rowptr_u) hipFree(op->rowptr_u);
   if (op->colind_u) hipFree(op->colind_u);
   if (op->vals_u) hipFree(op->vals_u);
-  if (op->tiles.tile_ptr) {
-    hipFree((void *)op->tiles.tile_ptr);
-    hipFree((void *)op->tiles.tile_cols);
-    hipFree((void *)op->tiles.lidx);
-    hipFree((void *)op->tiles.self_idx);
-  }
+  if (op->tiles.tile_row) hipFree((void *)op->tiles.tile_row);
+  if (op->tiles.tile_ptr) hipFree((void *)op->tiles.tile_ptr);
+  if (op->tiles.tile_cols) hipFree((void *)op->tiles.tile_cols);
+  if (op->tiles.lcol) hipFree((void *)op->tiles.lcol);
+  if (op->tiles.self_idx) hipFree((void *)op->tiles.self_idx);
   ctx_release(op->ctx);
   delete op;
   return SLQ_OK;
@@ -1041,10 +1137,16 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     p->alpha_pad = (size_t)env_int("SLQ_ALPHA_LDS_PAD", (per_cu_env > 0 || local) ? 0 : 65536);
   }
   {
-    // tiled passes: 1 workgroup per CU resident (8 wave-private LDS images), one panel at a time
-    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", 1));
+    // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
+    // per CU and panel in the grid, panel after panel
+    const int img_kib = op->tiles.tile_ptr ? (op->tiles.max_cols + 16) * (SLQ_TILE_DB ? 2 : 1) : 160;
+    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", std::max(1, std::min(4, 160 / std::max(img_kib, 1)))));
     int per_xcd_t = std::max(1, ctx->num_cus * per_cu_t / 8);
-    if (op->tiles.tile_ptr) per_xcd_t = std::min(per_xcd_t, std::max(1, op->tiles.tiles_per_xcd));
+    if (op->tiles.tile_ptr) {
+      int mn = 1 << 30;
+      for (int x = 0; x < 8; ++x) mn = std::min(mn, std::max(1, op->tiles.xcd_tile[x + 1] - op->tiles.xcd_tile[x]));
+      per_xcd_t = std::min(per_xcd_t, mn);
+    }
     p->nblkT = 8 * per_xcd_t;
   }
   memset(&p->acc, 0, sizeof(p->acc));
@@ -1236,11 +1338,18 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
   }
   for (const void *fn : fused_fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const void *tiled_fns[] = {(const void *)k_csr_pass_tiled<F, PASS_ALPHA, 0, 0, kTiledMaxR>, (const void *)k_csr_pass_tiled<F, PASS_ALPHA, 1, 1, kTiledMaxR>,
-                             (const void *)k_csr_pass_tiled<F, PASS_DOTS, 0, 0, kTiledMaxR>,  (const void *)k_csr_pass_tiled<F, PASS_DOTS, 1, 1, kTiledMaxR>,
-                             (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 0, 0, kTiledMaxR>, (const void *)k_csr_pass_tiled<F, PASS_UPDATE, 1, 1, kTiledMaxR>};
-  for (const void *fn : tiled_fns)
-    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if constexpr (L == 64) {
+    std::vector<const void *> tiled_fns = {
+        (const void *)k_csr_tile_pass<F, PASS_ALPHA, 0, 0>, (const void *)k_csr_tile_pass<F, PASS_ALPHA, 1, 0>,
+        (const void *)k_csr_tile_pass<F, PASS_UPDATE, 0, 0>, (const void *)k_csr_tile_pass<F, PASS_UPDATE, 1, 0>,
+#define TILE_RC(R)                                                                                              \
+  (const void *)k_csr_tile_pass<F, PASS_ADOTS, 0, R>, (const void *)k_csr_tile_pass<F, PASS_ADOTS, 1, R>,       \
+      (const void *)k_csr_tile_pass<F, PASS_UPDATE, 0, R>, (const void *)k_csr_tile_pass<F, PASS_UPDATE, 1, R>
+        TILE_RC(1), TILE_RC(2), TILE_RC(3), TILE_RC(4), TILE_RC(5), TILE_RC(6), TILE_RC(7), TILE_RC(8)};
+#undef TILE_RC
+    for (const void *fn : tiled_fns)
+      if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   return e;
 }
 static int set_kernel_attributes(slq_plan *p) {
@@ -1565,6 +1674,19 @@ static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStrea
   k_csr_pass<F, L, PASS, LP, RC, 0><<<grid, dim3(kBlock), lds, st>>>(args...);
 }
 
+// the same pass on workgroup tiles (wide panels only; slq_kernels.hpp: k_csr_tile_pass)
+template <typename F, int L, int PASS, int LP, int RC>
+static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStream_t st, int j, int xt) {
+  if constexpr (L == 64 && (PASS == PASS_ALPHA || PASS == PASS_ADOTS || PASS == PASS_UPDATE)) {
+    const slq_operator *op = p->op;
+    TileRanges xr;
+    for (int x = 0; x < 9; ++x) xr.first[x] = op->tiles.xcd_tile[x];
+    k_csr_tile_pass<F, PASS, LP, RC><<<grid, dim3(kBlock), lds, st>>>(p->n, op->rowptr, (const F *)op->vals, op->tiles.tile_row, op->tiles.tile_ptr,
+                                                                    op->tiles.tile_cols, op->tiles.lcol, op->tiles.self_idx, xr, op->tiles.max_cols, (F *)p->ring,
+                                                                    p->slot_stride, p->S, j, p->st.coefA, p->st.coefB, p->st.gamma, p->part, p->bpad, xt);
+  }
+}
+
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
 static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   if (p->ring32_on && p->nstale > 0) return fail(SLQ_EINVAL, "SLQ_RING32 does not combine with preloaded stale ring columns");
@@ -1608,40 +1730,34 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
-      // wide panels (one row per wave) with a tile index: gathered rows staged once per tile through LDS
-      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && p->sw.tiles && p->orth <= kTiledMaxR;
-      const size_t lds_tile = tiled ? (size_t)kWaves * op->tiles.max_cols * p->PW * p->esz : 0;  // one image per wave
+      // wide panels (one row per wave) of an operator with workgroup tiles (SLQ_TILES): the tile's distinct panel rows are
+      // staged once in LDS (k_csr_tile_pass); everything else about the sequence is the same
+      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && p->sw.tiles && !stored_u;
+      const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
-  DISPATCH(p->dtype, p->LPR,                                                                         \
-           (launch_csr_pass<F, L, PASS, LP, RCT>(pipe_on, (PASS == PASS_ALPHA ? gAf : gU), LDS, st, p->n, \
-               half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,                   \
-               (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S, j,        \
-               p->st.coefA, p->st.coefB, p->st.gamma, p->part, bp, XT)))
+  do {                                                                                               \
+    if (tiled)                                                                                       \
+      DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS, LP, RCT>(p, gT, lds0 + lds_tile, st, j, XT))); \
+    else                                                                                             \
+      DISPATCH(p->dtype, p->LPR,                                                                     \
+               (launch_csr_pass<F, L, PASS, LP, RCT>(pipe_on, (PASS == PASS_ALPHA ? gAf : gU), LDS, st, p->n, \
+                   half ? op->rowptr_u : op->rowptr, half ? op->colind_u : op->colind,               \
+                   (const F *)(half ? op->vals_u : op->vals), (F *)p->ring, p->slot_stride, S, j,    \
+                   p->st.coefA, p->st.coefB, p->st.gamma, p->part, bp, XT)));                        \
+  } while (0)
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
   do {                                                                                               \
-    if (tiled) {                                                                                     \
-      constexpr int TP = (PASS) == PASS_ADOTS ? PASS_DOTS : (PASS); /* the tiled kernels have no merged pass */ \
-      if (p->dtype == SLQ_F64)                                                                       \
-        k_csr_pass_tiled<double, TP, LP, SP, kTiledMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
-            p->n, op->rowptr, (const double *)op->vals, op->tiles, (double *)p->ring, p->slot_stride, S, \
-            j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
-      else                                                                                           \
-        k_csr_pass_tiled<float, TP, LP, SP, kTiledMaxR><<<gT, dim3(kBlock), (LDS) + lds_tile, st>>>( \
-            p->n, op->rowptr, (const float *)op->vals, op->tiles, (float *)p->ring, p->slot_stride, S, \
-            j, I0, RC, p->st.coefA, p->st.coefB, p->st.gamma + (size_t)(I0) * bp, p->part, bp);      \
-    } else {                                                                                         \
-      const bool half = PASS == PASS_ALPHA && op->rowptr_u != nullptr;                               \
-      switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                       \
-        case 0: CSR_PASS_RC(PASS, LP, ((PASS == PASS_DOTS || PASS == PASS_ADOTS) ? 1 : 0), LDS, XT); break; \
-        case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                 \
-        case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                 \
-        case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                 \
-        case 4: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 4), LDS, XT); break;                 \
-        case 5: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 5), LDS, XT); break;                 \
-        case 6: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 6), LDS, XT); break;                 \
-        case 7: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 7), LDS, XT); break;                 \
-        default: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 8), LDS, XT); break;                \
-      }                                                                                              \
+    const bool half = !tiled && PASS == PASS_ALPHA && op->rowptr_u != nullptr;                       \
+    switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                         \
+      case 0: CSR_PASS_RC(PASS, LP, ((PASS == PASS_DOTS || PASS == PASS_ADOTS) ? 1 : 0), LDS, XT); break; \
+      case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                   \
+      case 2: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 2), LDS, XT); break;                   \
+      case 3: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 3), LDS, XT); break;                   \
+      case 4: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 4), LDS, XT); break;                   \
+      case 5: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 5), LDS, XT); break;                   \
+      case 6: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 6), LDS, XT); break;                   \
+      case 7: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 7), LDS, XT); break;                   \
+      default: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 8), LDS, XT); break;                  \
     }                                                                                                \
   } while (0)
       // alpha pass: grid and residency cap (nblkF, alpha_pad) are chosen in slq_plan_create
@@ -1655,15 +1771,15 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const size_t fused_pad = tiled ? 0 : (size_t)(p->sw.fused_pad >= 0 ? p->sw.fused_pad : (p->pipelined ? 98304 : 65536));
       const bool pipe_on = p->pipelined && !tiled;
       // r >= 1: alpha comes out of the dots pass (PASS_ADOTS: two gather passes per step instead of three)
-      const bool merged = !tiled && r > 0 && p->sw.merged;
+      const bool merged = r > 0 && (tiled || p->sw.merged);  // (the tiled kernels have the merged form only)
       // cross term: the update pass of the previous step left W_c.W_p behind, so the alpha pass skips W_p
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
       const int su = stored_u ? 2 : 0;
-      const int xt_u = ((!tiled && !merged && p->sw.cross) ? 1 : 0) | su;
+      const int xt_u = ((!merged && p->sw.cross) ? 1 : 0) | su;
       if (merged) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,
-                 hipLaunchKernelGGL(k_fin_adots, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkU, j, r, orth_tol));
+                 hipLaunchKernelGGL(k_fin_adots, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkU, j, r, orth_tol));
       } else {
       PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xt_a); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xt_a); });
       PROFILED(p, SLQ_K_FINALIZE,
@@ -1675,7 +1791,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
                                     p->part, tiled ? p->nblkT : p->nblkU, j, 0, orth_tol));
       }
       }
-      const size_t ldsU = lds0 + fused_pad + (tiled ? (size_t)r * p->PW * p->esz : 0);  // the tiled kernel stages gamma in LDS
+      const size_t ldsU = lds0 + fused_pad;
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
                { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_u); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_u); });
 #undef CSR_PASS

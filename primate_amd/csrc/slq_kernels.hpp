@@ -64,7 +64,6 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
 constexpr int kMaxDeg = 512;
 constexpr int kFusedMaxR = 8;        // fused recompute passes handle up to this many reorth columns
-constexpr int kTiledMaxR = 4;        // ... and the experimental LDS-tiled variants up to this many
 #ifndef SLQ_UPD_UR
 #define SLQ_UPD_UR 2
 #endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
@@ -529,50 +528,67 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   }
 }
 
-// ---- tiled fused passes: gathered panel rows staged ONCE per row tile through LDS ----------------
-// The generic passes above re-gather every nonzero's panel row from L2: for the 5-point stencil
-// 7 KiB reach the CU per output row, 14 GB per launch, and the passes sit at the ~17 TB/s the
-// XCD L2s can deliver to the CUs for 1-KiB row gathers (MI355X_MICROARCH.md 'Indexed rows'), not
-// at the HBM rate. Here a workgroup takes TR consecutive rows, loads each DISTINCT column's panel
-// row once into an LDS tile (the column list of the tile is precomputed on the host when the
-// operator is created: slq.hip:build_row_tiles), and all nonzeros read LDS. For the stencil that is
-// (3 TR + 2)/TR + 1 = 4.1 KiB per row instead of 7. `lidx` holds, per nonzero, the position of its
-// column in the tile's list (uint16), replacing the 4-byte column index in the CSR stream.
-struct RowTiles {
+// ---- tiled fused passes: a workgroup tile's distinct panel rows staged ONCE in LDS (opt-in, SLQ_TILES) -----------
+// Every gather pass is bound by the bytes its CUs' vector-memory pipes carry per row: 6-7 gathered
+// panel rows of 1 KiB per output row on the 7-point grid, 4-5 on the 5-point one, next to 2-3 KiB of streams. Rows are
+// therefore grouped into compact CLUSTERS (slq.hip: build_clusters - greedy breadth-first blobs of <= kTileRows rows
+// whose rows and columns together span <= kTileCols distinct panel rows: 2.8-3.0 per row on the 7-point grid, 1.7 on
+// the 5-point one), a cluster is one workgroup TILE, and the tile's distinct rows are fetched once, by LDS-DMA
+// (global_load_lds_dwordx4: one wave instruction lands one 1-KiB panel row in the tile image, no registers), after
+// which every nonzero - and the row-local operand W_c[row] - is an LDS read. `lcol` holds, per nonzero, the position
+// of its column in its tile's list (it replaces colind in the CSR stream); `self_idx` the position of each row itself.
+// One panel row per wave instruction, i.e. LPR = 64 panels only. One workgroup per CU with TWO images (2 x 72 KiB):
+// the next tile is staged while the current one is computed. The arithmetic per row is that of k_csr_pass, products summed in CSR order.
+struct TileMeta {
+  const int32_t *tile_row;   // [ntiles + 1] first (stored) row of each tile
   const int32_t *tile_ptr;   // [ntiles + 1] offsets into tile_cols
-  const int32_t *tile_cols;  // distinct global columns of each tile, ascending
-  const uint16_t *lidx;      // [nnz] local column position of every nonzero
-  const uint16_t *self_idx;  // [n] local position of the row's own index (always in the list)
-  int rows_per_tile;         // TR
-  int max_cols;              // largest tile list (LDS sizing)
-  int tiles_per_xcd;         // tiles in one XCD's chunk (chunk = tiles_per_xcd * TR rows)
+  const int32_t *tile_cols;  // distinct stored row indices each tile reads, ascending (+ kCsrPad spare entries)
+  const int32_t *lcol;       // [nnz + kCsrPad] position of every nonzero's column in its tile's list
+  const int32_t *self_idx;   // [n] position of the row itself
+  int32_t xcd_tile[9];       // tiles of XCD chunk x: [xcd_tile[x], xcd_tile[x + 1])
+  int max_cols;              // longest list (LDS sizing)
 };
+struct TileRanges {
+  int32_t first[9];  // TileMeta::xcd_tile, by value in the kernel arguments
+};
+#ifndef SLQ_TILE_DB
+#define SLQ_TILE_DB 0
+#endif
+constexpr int kTileRows = 24;  // rows per tile at most (3 per wave)
+constexpr int kTileCols = 72;  // distinct panel rows per tile at most: 72 KiB of LDS image
 
-template <typename F, int PASS, int LP, int SP, int DCH>
-__global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
-    int n, const int32_t *__restrict__ rowptr, const F *__restrict__ vals, RowTiles rt, F *ring,
-    int64_t slot_stride, int S, int j, int i0, int rc, const double *__restrict__ coefA,
-    const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
-    int bpad) {
+template <typename F, int PASS, int NTP, int RC>
+__global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
+    int n, const int32_t *__restrict__ rowptr, const F *__restrict__ vals,
+    // (the lists are separate __restrict__ parameters, not a struct of pointers: only then are they provably read-only
+    // and wave-uniform accesses to them scalar loads - as vector loads their waits would also drain the LDS-DMAs)
+    const int32_t *__restrict__ tile_row, const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ tile_cols,
+    const int32_t *__restrict__ lcol, const int32_t *__restrict__ self_idx, TileRanges xr, int max_cols, F *ring, int64_t slot_stride,
+    int S, int j, const double *__restrict__ coefA, const double *__restrict__ coefB,
+    const double *__restrict__ gamma /* PASS_UPDATE: [RC][bpad] */, double *__restrict__ part, int bpad, int xt) {
   using VF = typename VecT<F>::type;
   constexpr int LPR = 64;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
+  constexpr int NX = RC > 2 ? RC - 2 : 1;
+  static_assert(PASS == PASS_ALPHA || PASS == PASS_ADOTS || PASS == PASS_UPDATE, "tiled passes: alpha, merged dots, update");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  double *red = (double *)lds_raw;                                  // kWaves*64*V doubles
-  F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);        // PASS_UPDATE: rc * PW
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // WAVE-PRIVATE tile image: no workgroup barrier inside the row loop, every wave runs its own
-  // load -> compute chain (the barrier-coupled version exposed one HBM latency per tile and workgroup)
-  F *tile = gl + (PASS == PASS_UPDATE ? rc * PW : 0) + (size_t)wave * rt.max_cols * PW;
+  double *red = (double *)lds_raw;                             // kWaves*64*V doubles
+  F *tbuf = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V);  // tile image: max_cols rows of PW
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + lane * V;
-  const int first = (j == 0);
-  const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  xt &= 1;
+  const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
+  const F *wcl = ring + (int64_t)(j % S) * slot_stride + poff;  // this lane's part of W_c's panel rows
   const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
   F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
-  const F *U0 = ring + poff;
+  const F *ux[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) ux[i] = ring + (int64_t)ring_slot(j - 2 - i, S) * slot_stride + poff;
   const int colbase = panel * PW + lane * V;
   VF sc, cp, cb = (VF)(F)0;
+  VF gm[RC > 0 ? RC : 1];
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     sc[v] = (F)coefA[colbase + v];
@@ -580,107 +596,143 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass_tiled(
     if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
   }
   if (PASS == PASS_UPDATE) {
-    for (int t = threadIdx.x; t < rc * PW; t += kBlock)
-      gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RC; ++i)
+#pragma unroll
+      for (int v = 0; v < V; ++v) gm[i][v] = (F)gamma[(int64_t)i * bpad + colbase + v];
   }
-  const int TR = rt.rows_per_tile;
+  VF acc1 = (VF)(F)0, accx = (VF)(F)0;
+  VF dacc[RC > 0 ? RC : 1], gacc[RC > 0 ? RC : 1];
+#pragma unroll
+  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = gacc[i] = (VF)(F)0;
   const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
-  VF acc1 = (VF)(F)0;
-  VF dacc[PASS == PASS_DOTS ? DCH : 1];
-  if (PASS == PASS_DOTS) {
+  constexpr int MR = (kTileRows + kWaves - 1) / kWaves;  // rows of a tile per wave at most
+  const size_t img = (size_t)max_cols * PW;               // elements of one tile image; two images: double buffering
+  // Software pipeline over this workgroup's tiles t, t + nbl, ...: while tile t is computed out of image A, the LDS-DMAs
+  // of tile t + nbl fill image B and its row-local streams (W_p, ring columns) are on their way into registers. One
+  // barrier per tile: it publishes image t AND says that every wave is done reading the image the next DMAs overwrite.
+  auto stage = [&](int t, F *buf) {
+    const int c0 = tile_ptr[t], D = tile_ptr[t + 1] - c0;
+    const int dper = (D + kWaves - 1) / kWaves;
+    const int d_lo = wave * dper, d_hi = min(D, d_lo + dper);
+    for (int d = d_lo; d < d_hi; d += 8) {
+      const csr_i8 cols = *(const csr_i8 *)(tile_cols + c0 + d);  // (reads past d_hi are spare or later entries: unused)
 #pragma unroll
-    for (int i = 0; i < DCH; ++i) dacc[i] = (VF)(F)0;
-  }
-  // Software pipeline over this wave's tiles: the global loads of tile k+1 (distinct panel rows and the
-  // row-local W_p rows) are issued BEFORE tile k is consumed from the LDS image and are parked in the
-  // image only afterwards, so their HBM/L2 latency overlaps the compute of tile k.
-  constexpr int MAXC = 16, MAXTR = 4;
-  const int tstep = nbl * kWaves;
-  int tl = bl * kWaves + wave;
-  VF xs[MAXC], xpn[MAXTR];
-  int ncols_n = 0, row0_n = n;
-  auto issue = [&](int tli) {
-    ncols_n = 0;
-    row0_n = n;
-    if (tli < rt.tiles_per_xcd) {
-      const int t = __builtin_amdgcn_readfirstlane(xcd * rt.tiles_per_xcd + tli);
-      if (t * TR < n) {
-        row0_n = t * TR;
-        const int c_begin = rt.tile_ptr[t];
-        ncols_n = rt.tile_ptr[t + 1] - c_begin;
+      for (int k = 0; k < 8; ++k)
+        if (d + k < d_hi)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)cols[k] * PW),
+                                           (__attribute__((address_space(3))) void *)(buf + (size_t)(d + k) * PW), 16, 0, 0);
+    }
+  };
+  VF xpn[MR], un[MR][NX];  // row-local operands of the NEXT tile's rows of this wave
+  auto fetch_rows = [&](int t) {
+    const int r_lo = tile_row[t], r_hi = tile_row[t + 1];
 #pragma unroll
-        for (int u = 0; u < MAXC; ++u)
-          if (u < ncols_n) xs[u] = *(const VF *)(wc + (int64_t)rt.tile_cols[c_begin + u] * PW);
+    for (int i = 0; i < MR; ++i) {
+      const int row = r_lo + wave + i * kWaves;
+      if (row < r_hi) {
+        const int64_t ro = (int64_t)row * PW;
+        if (!first) xpn[i] = stream_load<NTP>((const VF *)(wp + ro));
+        if (PASS != PASS_ALPHA && RC > 2) {
 #pragma unroll
-        for (int q = 0; q < MAXTR; ++q) {
-          xpn[q] = (VF)(F)0;
-          if (!first && q < TR && row0_n + q < n) xpn[q] = stream_load<LP>((const VF *)(wp + (int64_t)(row0_n + q) * PW));
+          for (int q = 0; q < NX; ++q) un[i][q] = stream_load<NTP>((const VF *)(ux[q] + ro));
         }
       }
     }
   };
-  issue(tl);
-  while (row0_n < n) {
-    // park the prefetched tile in the LDS image
-    const int row0 = row0_n, ncols = ncols_n;
+  int t = xr.first[xcd] + bl;
+  const int t_end = xr.first[xcd + 1];
+  int cur = 0;
+  constexpr bool kDB = SLQ_TILE_DB != 0;  // two images per workgroup (1 workgroup per CU) or one (2-4 per CU)
+  if (kDB && t < t_end) {
+    stage(t, tbuf);
+    fetch_rows(t);
+  }
+  for (; t < t_end; t += nbl) {
+    if (!kDB) {
+      stage(t, tbuf);
+      fetch_rows(t);
+    }
+    __syncthreads();  // (drains this wave's DMAs and loads first: vmcnt(0))
+    const F *xl = tbuf + (size_t)cur * img + lane * V;  // this lane's part of the current image's rows
+    VF xpc[MR], uc[MR][NX];
 #pragma unroll
-    for (int u = 0; u < MAXC; ++u)
-      if (u < ncols) *(VF *)(tile + u * PW + lane * V) = xs[u];
-    VF xpc[MAXTR];
+    for (int i = 0; i < MR; ++i) {
+      xpc[i] = xpn[i];
 #pragma unroll
-    for (int q = 0; q < MAXTR; ++q) xpc[q] = xpn[q];
-    tl += tstep;
-    issue(tl);  // next tile's loads fly while this one is consumed
+      for (int q = 0; q < NX; ++q) uc[i][q] = un[i][q];
+    }
+    const int tn = t + nbl;
+    if (kDB && tn < t_end) {
+      stage(tn, tbuf + (size_t)(cur ^ 1) * img);
+      fetch_rows(tn);
+    }
+    const int r_lo = tile_row[t], r_hi = tile_row[t + 1];
 #pragma unroll
-    for (int rr = 0; rr < MAXTR; ++rr) {
-      const int row = row0 + rr;
-      if (rr >= TR || row >= n) break;
-      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+    for (int i = 0; i < MR; ++i) {
+      const int row = r_lo + wave + i * kWaves;
+      if (row >= r_hi) break;
       const int64_t ro = (int64_t)row * PW;
-      const VF xp = xpc[rr];
-      const VF xc = *(const VF *)(tile + (int)rt.self_idx[row] * PW + lane * V);
+      const int p0 = rowptr[row], p1 = rowptr[row + 1];
+      const int si = self_idx[row];
+      const VF xp = first ? (VF)(F)0 : xpc[i];
+      const VF xc = *(const VF *)(xl + (size_t)si * PW);
       VF acc = (VF)(F)0;
-      for (int p = p0; p < p1; ++p)
-        acc += vals[p] * *(const VF *)(tile + (int)rt.lidx[p] * PW + lane * V);
+      for (int pb = p0; pb < p1; pb += 8) {
+        const int cnt = p1 - pb;
+        const csr_i8 lc = *(const csr_i8 *)(lcol + pb);
+        const typename CsrVals<F>::type a8 = *(const typename CsrVals<F>::type *)(vals + pb);
+        VF x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < cnt) x[k] = *(const VF *)(xl + (size_t)lc[k] * PW);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < cnt) acc += a8[k] * x[k];
+      }
       VF w = sc * acc;
       if (!first) w -= cp * xp;
       if (PASS == PASS_ALPHA) {
         acc1 += (sc * xc) * w;
+      } else if (PASS == PASS_ADOTS) {
+        acc1 += (sc * xc) * w;
+        if constexpr (RC > 1) {
+          dacc[1] += xp * w;
+          gacc[1] += xp * xc;
+        }
+#pragma unroll
+        for (int q = 2; q < RC; ++q) {
+          dacc[q] += uc[i][q - 2] * w;
+          gacc[q] += uc[i][q - 2] * xc;
+        }
       } else {
         w -= cb * xc;
-        VF u[DCH];
+        if constexpr (RC > 0) w -= gm[0] * xc;
+        if constexpr (RC > 1) w -= gm[1] * xp;
 #pragma unroll
-        for (int i = 0; i < DCH; ++i)
-          if (i < rc) {
-            const int ii = i0 + i;
-            u[i] = (ii == 0) ? xc
-                             : ((ii == 1) ? xp
-                                          : stream_load<LP>((const VF *)(U0 + (int64_t)ring_slot(j - ii, S) * slot_stride + ro)));
-          }
-        if (PASS == PASS_DOTS) {
-#pragma unroll
-          for (int i = 0; i < DCH; ++i)
-            if (i < rc) dacc[i] += u[i] * w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < DCH; ++i)
-            if (i < rc) w -= *(const VF *)(gl + i * PW + lane * V) * u[i];
-          stream_store<SP>((VF *)(wn + ro), w);
-          acc1 += w * w;
-        }
+        for (int q = 2; q < RC; ++q) w -= gm[q] * uc[i][q - 2];
+        stream_store<NTP>((VF *)(wn + ro), w);
+        acc1 += w * w;
+        accx += w * xc;
       }
     }
+    if (kDB) cur ^= 1;
+    else __syncthreads();  // single image: every wave is done with it before the next tile's DMAs land
   }
-  __syncthreads();
+  __syncthreads();  // the reductions below reuse LDS
   const int64_t nblk = gridDim.x;
-  if (PASS == PASS_DOTS) {
+  if (PASS == PASS_ADOTS) {
+    // slab 0: alpha partials; slabs 1..RC-1: d_i; slabs RC..2RC-2: g_i
+    block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
 #pragma unroll
-    for (int i = 0; i < DCH; ++i)
-      if (i < rc)
-        block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+    for (int i = 1; i < RC; ++i) {
+      block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+      block_reduce_columns<F, LPR>(gacc[i], red, part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
+    }
   } else {
     block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+    if (PASS == PASS_UPDATE && xt)
+      block_reduce_columns<F, LPR>(accx, red, part + (nblk + blockIdx.x) * bpad + panel * PW);
   }
 }
 

@@ -614,19 +614,39 @@ def test_opt_in_fp32_archive_ring(oracle, eng, monkeypatch):
 
 
 def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
-	"""SLQ_TILES=1: the experimental LDS-staged fused passes (k_csr_pass_tiled) give the generic
-	passes' results to rounding, for both tile heights and with/without reorthogonalisation."""
-	A = laplacian_2d(70)  # n = 4900 (not a multiple of the tile height), wide panel (P > 64)
+	"""SLQ_TILES=1: rows regrouped into compact clusters, every cluster one workgroup tile whose distinct panel rows are
+	staged once in LDS (k_csr_tile_pass). Same per-probe values as the oracle for every ring-column count of the fused
+	steps, both dtypes, 2-D and 3-D grids (with the XCD reordering on top), tile heights 24 / 16 / 7, a matrix with empty
+	rows; operators whose tiles would share nothing keep the generic passes."""
 	rng = np.random.default_rng(9)
-	X = np.asfortranarray(np.floor(rng.random((A.shape[0], 130)) * 2) * 2 - 1)
-	ref = {o: oracle.quad_batch(A, X[:, :6], 14, o, fun="log", fresh_q=True) for o in (0, 3)}
-	for tr in ("4", "2"):
-		monkeypatch.setenv("SLQ_TILES", "1")
+	monkeypatch.setenv("SLQ_TILES", "1")
+	cases = [(laplacian_2d(70), "24", "0"), (laplacian_3d(17), "16", "2"), (laplacian_2d(66), "7", "0")]
+	for A, tr, reorder in cases:
 		monkeypatch.setenv("SLQ_TILE_ROWS", tr)
+		monkeypatch.setenv("SLQ_REORDER", reorder)
+		n = A.shape[0]
+		X = np.asfortranarray(np.floor(rng.random((n, 130)) * 2) * 2 - 1)  # wide panel (P > 64), 2 panels
+		cols = [0, 1, 63, 64, 127, 129]
 		op = eng.DeviceOperator(A)
-		for o in (0, 3):
-			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[:6], ref[o], rtol=1e-10)
+		plan = eng.LanczosPlan(op, 130, 14, 3)
+		assert plan.describe()["reordered"] == 1  # the clusters are a row order of their own
+		plan.close()
+		for o in (0, 1, 2, 3, 5, 8):
+			ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, o, fun="log", fresh_q=True)
+			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[cols], ref, rtol=1e-10, err_msg=f"n={n} orth={o}")
 		op.close()
+	A32 = laplacian_2d(70).astype(np.float32)
+	X32 = np.asfortranarray(np.floor(rng.random((A32.shape[0], 260)) * 2) * 2 - 1).astype(np.float32)
+	op = eng.DeviceOperator(A32)
+	ref = oracle.quad_batch(A32, np.asfortranarray(X32[:, :4]), 14, 3, fun="log", fresh_q=True)
+	np.testing.assert_allclose(eng.quad_batch(op, X32, 14, 3, fun="log")[:4], ref, rtol=3e-4)
+	op.close()
+	## irregular graph with empty rows: tiles are either feasible and correct, or declined
+	G = random_spd_graph(6000, 3.0, seed=5)
+	Xg = np.asfortranarray(rng.standard_normal((6000, 70)))
+	op = eng.DeviceOperator(G)
+	np.testing.assert_allclose(eng.quad_batch(op, Xg, 12, 3, fun="log")[:5], oracle.quad_batch(G, np.asfortranarray(Xg[:, :5]), 12, 3, fun="log", fresh_q=True), rtol=1e-10)
+	op.close()
 
 
 def test_tall_skinny_mfma_products(eng):
