@@ -115,8 +115,9 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 			out["axpy_norm"] += 3 * vec  # read w, q_c; write w
 			launches["axpy_norm"] += 1
 		else:
-			for i0 in range(0, r, chunk):
-				rc = min(chunk, r - i0)
+			ch = 8 if half else chunk  # slq_kernels.hpp: kReorthChunk32 / kReorthChunk
+			for i0 in range(0, r, ch):
+				rc = min(ch, r - i0)
 				out["reorth_dot"] += (cols(i0, i0 + rc) + (2 if i0 == 0 else 1)) * vec
 				launches["reorth_dot"] += 1
 			out["reorth_update"] += (cols(0, r) + 2 + (0.5 if half else 0.0)) * vec

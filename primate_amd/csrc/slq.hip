@@ -1227,9 +1227,9 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 // Kernels that may be launched with more than the default 64 KiB of dynamic LDS (gamma staging):
 // raise their limit once, outside any stream capture.
 template <typename F, int L> static hipError_t raise_lds_limits() {
-  hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void *)k_reorth_update<F, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if constexpr (std::is_same<F, double>::value)
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_reorth_update<F, L, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_reorth_update32<L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   // fused passes: LDS padding caps their residency (SLQ_ALPHA_LDS_PAD experiments; dots/update: 2 per CU)
   std::vector<const void *> fused_fns = {
       (const void *)k_csr_pass<F, L, PASS_ALPHA, 0, 0, 0>,
@@ -1641,25 +1641,25 @@ static int quadrature_lanes(int deg) {
 template <typename F, int L> static inline void launch_reorth_dot(slq_plan *p, dim3 gS, hipStream_t st, int j, int i0, int rc) {
   if constexpr (std::is_same<F, double>::value) {
     if (p->ring32_on) {
-      k_reorth_dot<F, L, 1><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB,
-                                                        p->part, p->bpad, p->ring32, p->slot_stride, p->S32);
+      k_reorth_dot32<L><<<gS, dim3(kBlock), 0, st>>>(p->n, (double *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB,
+                                                    p->part, p->bpad, p->ring32, p->slot_stride, p->S32);
       return;
     }
   }
-  k_reorth_dot<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB,
-                                                    p->part, p->bpad, (const float *)nullptr, 0, 1);
+  k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB, p->part, p->bpad);
 }
 template <typename F, int L>
 static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds, hipStream_t st, int j, int i0, int rc, int archive) {
   if constexpr (std::is_same<F, double>::value) {
     if (p->ring32_on) {
-      k_reorth_update<F, L, 1><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
-                                                            p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, p->ring32, p->slot_stride, p->S32, archive);
+      const size_t lds32 = sizeof(double) * kWaves * 64 * 4 + (size_t)rc * p->PW * sizeof(double);
+      k_reorth_update32<L><<<gS, dim3(kBlock), lds32, st>>>(p->n, (double *)p->ring, p->slot_stride, p->S, j, i0, rc,
+                                                          p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, p->ring32, p->slot_stride, p->S32, archive);
       return;
     }
   }
-  k_reorth_update<F, L, 0><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc,
-                                                        p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, (float *)nullptr, 0, 1, 0);
+  k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, p->st.gamma + (size_t)i0 * p->bpad,
+                                                     p->part, p->bpad);
 }
 
 // one fused CSR pass; the pipelined row loop exists for one-row-per-wave panels (L == 64) and not for the alpha pass
@@ -1847,17 +1847,18 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       for (int i = 0; i < r; ++i) {
         PROFILED(p, SLQ_K_REORTH_DOT,
                  DISPATCH(p->dtype, p->LPR,
-                          (k_reorth_dot<F, L, 0><<<gS, dim3(kBlock), 0, st>>>(p->n,
+                          (k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n,
                                               (F *)p->ring, p->slot_stride, S, j, i, 1, (int)(i == 0),
-                                              p->st.coefB, p->part, bp, (const float *)nullptr, 0, 1))));
+                                              p->st.coefB, p->part, bp))));
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, 1), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i, orth_tol));
         SLQ_TRY(launch_reorth_update_range(p, j, i, i + 1));
       }
     } else {
-      for (int i0 = 0; i0 < r; i0 += kReorthChunk) {
-        const int rc = std::min(kReorthChunk, r - i0);
+      const int dot_chunk = p->ring32_on ? kReorthChunk32 : kReorthChunk;  // reorth columns per dots launch
+      for (int i0 = 0; i0 < r; i0 += dot_chunk) {
+        const int rc = std::min(dot_chunk, r - i0);
         PROFILED(p, SLQ_K_REORTH_DOT,
                  DISPATCH(p->dtype, p->LPR,
                           (launch_reorth_dot<F, L>(p, gS, st, j, i0, rc))));

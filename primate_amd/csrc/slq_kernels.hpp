@@ -1101,32 +1101,12 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
 // orthogonalisation pass after the three-term step), r_chunk <= kReorthChunk columns per launch
 // so the accumulators stay in registers.
 // ring: base of slot 0; vector t lives in slot t % S; slot stride = NP*n*PW elements.
-// A32 (opt-in, fp64 only: SLQ_RING32): the fp64 ring holds only the three live vectors (slots t % 3) and
-// every finished vector is also kept as fp32 in an archive ring (slot t % S32); reorthogonalisation columns
-// i >= 2 (vectors j-2 and older) are read from the archive - half the bytes - and accumulated in fp64.
-template <typename F, int LPR, int A32>
-__device__ __forceinline__ typename VecT<F>::type ring_column(const F *U0, int64_t slot_stride, int S, const float *R32,
-                                                              int64_t stride32, int S32, int64_t poff32, int t, int gi, int64_t ro) {
-  using VF = typename VecT<F>::type;
-  if (A32 && gi >= 2) {
-    typedef float f2_t __attribute__((ext_vector_type(2)));
-    const f2_t x = *(const f2_t *)(R32 + (int64_t)ring_slot(t, S32) * stride32 + poff32 + ro);
-    VF v;
-    v[0] = (F)x[0];
-    v[1] = (F)x[1];
-    return v;
-  }
-  return *(const VF *)(U0 + (int64_t)ring_slot(t, S) * slot_stride + ro);
-}
-
-template <typename F, int LPR, int A32>
+template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_reorth_dot(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int rc, int apply_axpy,
-    const double *__restrict__ coefB, double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad,
-    const float *__restrict__ ring32, int64_t stride32, int S32) {
+    const double *__restrict__ coefB, double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
-  static_assert(!A32 || V == 2, "the fp32 archive exists for fp64 plans only");
   __shared__ double red[kWaves * 64 * V];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
@@ -1155,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
     VF u[kReorthChunk];
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
-      if (i < rc) u[i] = ring_column<F, LPR, A32>(U0, slot_stride, S, ring32, stride32, S32, poff, j - i0 - i, i0 + i, ro);
+      if (i < rc) u[i] = *(const VF *)(U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride + ro);
 #pragma unroll
     for (int i = 0; i < kReorthChunk; ++i)
       if (i < rc) dacc[i] += u[i] * w;
@@ -1171,11 +1151,11 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
 // ---- sweep C: w -= sum_i gamma_i * W_{t_i} ; partN += w^2 ----------------------------------------
 // gamma[i][col] (coefficient on the UNNORMALISED ring vector; zero where the reference's skip
 // thresholds apply, lanczos.h:62) is staged in LDS once per block: r * PW doubles.
-template <typename F, int LPR, int A32>
+template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_reorth_update(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int r,
     const double *__restrict__ gamma /* [r][bpad], already offset to column i0 */,
-    double *__restrict__ partN, int bpad, float *ring32, int64_t stride32, int S32, int archive /* also store w as fp32 */) {
+    double *__restrict__ partN, int bpad) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   constexpr int UR = SLQ_UPD_UR;
@@ -1191,7 +1171,6 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
   __syncthreads();
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
-  float *W32 = A32 ? ring32 + (int64_t)ring_slot(j + 1, S32) * stride32 + poff : nullptr;
   VF nacc = (VF)(F)0;
   // UR CONSECUTIVE row groups per wave and iteration (one contiguous UR*RPW*PW*sizeof(F) block):
   // the gamma read from LDS is amortised over UR rows and UR loads per column are in flight.
@@ -1206,10 +1185,11 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       w[u] = *(const VF *)(W + ro[u]);
     }
     for (int i = 0; i < r; ++i) {
+      const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
       const VF gm = *(const VF *)(gl + i * PW + cl * V);
       VF x[UR];
 #pragma unroll
-      for (int u = 0; u < UR; ++u) x[u] = ring_column<F, LPR, A32>(U0, slot_stride, S, ring32, stride32, S32, poff, j - i0 - i, i0 + i, ro[u]);
+      for (int u = 0; u < UR; ++u) x[u] = *(const VF *)(U + ro[u]);
 #pragma unroll
       for (int u = 0; u < UR; ++u) w[u] -= gm * x[u];
     }
@@ -1218,18 +1198,164 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       const int row = r0 + u * RPW;
       if (row < n) {
         *(VF *)(W + ro[u]) = w[u];
-        if (A32 && archive) {
-          typedef float f2_t __attribute__((ext_vector_type(2)));
-          f2_t y;
-          y[0] = (float)w[u][0];
-          y[1] = (float)w[u][V - 1];
-          *(f2_t *)(W32 + ro[u]) = y;
-        }
         nacc += w[u] * w[u];
       }
     }
   }
   block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
+}
+
+// ---- opt-in fp32 archive of finished Lanczos vectors (SLQ_RING32, fp64 plans) ---------------------
+// The fp64 ring holds only the three live vectors (slots t % 3); every finished vector is also kept as fp32 in an archive
+// ring (slot t % S32, same panel layout). Reorthogonalisation columns i >= 2 (vectors j-2 and older) are read from the
+// archive - half the bytes - and accumulated in fp64. For the archive rows to be read at full width (16 bytes per lane)
+// these sweeps use their own lane layout: a lane owns FOUR probe columns (4 floats of the archive = one 16-byte load, 4
+// doubles of an fp64 vector = two), LR = PW/4 lanes per row, RW = 64/LR rows per wave instruction.
+typedef double d2a_t __attribute__((ext_vector_type(2)));
+typedef float f4a_t __attribute__((ext_vector_type(4)));
+#ifndef SLQ_CHUNK32
+#define SLQ_CHUNK32 8
+#endif
+constexpr int kReorthChunk32 = SLQ_CHUNK32;  // reorth columns per dots launch (4 accumulators per column and lane)
+
+template <int LPR> struct Geo32 {
+  static constexpr int PW = LPR * 2, LR = PW / 4, RW = 64 / LR;
+};
+// column sums of 4 partials per lane over the RW row groups of a wave and the waves of the block, fixed order
+template <int LPR>
+__device__ __forceinline__ void block_reduce_columns4(const double (&acc)[4], double *red /* kWaves*64*4 */, double *out) {
+  constexpr int PW = Geo32<LPR>::PW, LR = Geo32<LPR>::LR, RW = Geo32<LPR>::RW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[(wave * 64 + lane) * 4 + v] = acc[v];
+  __syncthreads();
+  if ((int)threadIdx.x < PW) {
+    const int t = threadIdx.x, c4 = t / 4, v = t % 4;
+    double s = 0.0;
+    for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+      for (int g = 0; g < RW; ++g) s += red[(w * 64 + g * LR + c4) * 4 + v];
+    out[t] = s;
+  }
+  __syncthreads();
+}
+// ring column gi of step j as 4 doubles: W_c / W_p from the fp64 ring, older vectors from the archive
+__device__ __forceinline__ void ring_column4(const double *ring, int64_t slot_stride, int S, const float *ring32, int64_t stride32, int S32,
+                                             int64_t off, int t, int gi, double (&u)[4]) {
+  if (gi >= 2) {
+    const f4a_t x = *(const f4a_t *)(ring32 + (int64_t)ring_slot(t, S32) * stride32 + off);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) u[v] = (double)x[v];
+  } else {
+    const double *p = ring + (int64_t)ring_slot(t, S) * slot_stride + off;
+    const d2a_t a = *(const d2a_t *)p, b = *(const d2a_t *)(p + 2);
+    u[0] = a[0]; u[1] = a[1]; u[2] = b[0]; u[3] = b[1];
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_reorth_dot32(
+    int n, double *ring, int64_t slot_stride, int S, int j, int i0, int rc, int apply_axpy, const double *__restrict__ coefB,
+    double *__restrict__ partD /* [rc][nblk][bpad] */, int bpad, const float *__restrict__ ring32, int64_t stride32, int S32) {
+  constexpr int PW = Geo32<LPR>::PW, LR = Geo32<LPR>::LR, RW = Geo32<LPR>::RW;
+  __shared__ double red[kWaves * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LR, c4 = lane % LR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + c4 * 4;
+  double *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const double *Wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  double cb[4] = {0.0, 0.0, 0.0, 0.0};
+  if (apply_axpy) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cb[v] = coefB[panel * PW + c4 * 4 + v];
+  }
+  double dacc[kReorthChunk32][4];
+#pragma unroll
+  for (int i = 0; i < kReorthChunk32; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dacc[i][v] = 0.0;
+  const int stride = gridDim.x * kWaves * RW;
+  for (int row = (blockIdx.x * kWaves + wave) * RW + g; row < n; row += stride) {
+    const int64_t ro = (int64_t)row * PW;
+    d2a_t wa = *(const d2a_t *)(W + ro), wb = *(const d2a_t *)(W + ro + 2);
+    if (apply_axpy) {
+      const d2a_t ca = *(const d2a_t *)(Wc + ro), cc = *(const d2a_t *)(Wc + ro + 2);
+      wa[0] -= cb[0] * ca[0]; wa[1] -= cb[1] * ca[1]; wb[0] -= cb[2] * cc[0]; wb[1] -= cb[3] * cc[1];
+      *(d2a_t *)(W + ro) = wa;
+      *(d2a_t *)(W + ro + 2) = wb;
+    }
+    const double w[4] = {wa[0], wa[1], wb[0], wb[1]};
+    double u[kReorthChunk32][4];
+#pragma unroll
+    for (int i = 0; i < kReorthChunk32; ++i)
+      if (i < rc) ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - i, i0 + i, u[i]);
+#pragma unroll
+    for (int i = 0; i < kReorthChunk32; ++i)
+      if (i < rc) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dacc[i][v] += u[i][v] * w[v];
+      }
+  }
+  const int64_t nblk = gridDim.x;
+#pragma unroll
+  for (int i = 0; i < kReorthChunk32; ++i)
+    if (i < rc) block_reduce_columns4<LPR>(dacc[i], red, partD + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void k_reorth_update32(
+    int n, double *ring, int64_t slot_stride, int S, int j, int i0, int r, const double *__restrict__ gamma /* [r][bpad], offset to i0 */,
+    double *__restrict__ partN, int bpad, float *ring32, int64_t stride32, int S32, int archive /* w is final: store it as fp32 too */) {
+  constexpr int PW = Geo32<LPR>::PW, LR = Geo32<LPR>::LR, RW = Geo32<LPR>::RW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double *red = (double *)lds_raw;               // kWaves*64*4 doubles
+  double *gl = red + kWaves * 64 * 4;            // r * PW
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / LR, c4 = lane % LR;
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + c4 * 4;
+  for (int t = threadIdx.x; t < r * PW; t += kBlock) gl[t] = gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+  __syncthreads();
+  double *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  float *W32 = ring32 + (int64_t)ring_slot(j + 1, S32) * stride32 + poff;
+  double nacc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int stride = gridDim.x * kWaves * RW;
+  for (int row = (blockIdx.x * kWaves + wave) * RW + g; row < n; row += stride) {
+    const int64_t ro = (int64_t)row * PW;
+    const d2a_t wa = *(const d2a_t *)(W + ro), wb = *(const d2a_t *)(W + ro + 2);
+    double w[4] = {wa[0], wa[1], wb[0], wb[1]};
+    int i = 0;
+    for (; i + 4 <= r; i += 4) {  // four columns' loads in flight
+      double u[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - i - q, i0 + i + q, u[q]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const d2a_t ga = *(const d2a_t *)(gl + (i + q) * PW + c4 * 4), gb = *(const d2a_t *)(gl + (i + q) * PW + c4 * 4 + 2);
+        w[0] -= ga[0] * u[q][0]; w[1] -= ga[1] * u[q][1]; w[2] -= gb[0] * u[q][2]; w[3] -= gb[1] * u[q][3];
+      }
+    }
+    for (; i < r; ++i) {
+      double u[4];
+      ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - i, i0 + i, u);
+      const d2a_t ga = *(const d2a_t *)(gl + i * PW + c4 * 4), gb = *(const d2a_t *)(gl + i * PW + c4 * 4 + 2);
+      w[0] -= ga[0] * u[0]; w[1] -= ga[1] * u[1]; w[2] -= gb[0] * u[2]; w[3] -= gb[1] * u[3];
+    }
+    d2a_t oa, ob;
+    oa[0] = w[0]; oa[1] = w[1]; ob[0] = w[2]; ob[1] = w[3];
+    *(d2a_t *)(W + ro) = oa;
+    *(d2a_t *)(W + ro + 2) = ob;
+    if (archive) {
+      f4a_t y;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) y[v] = (float)w[v];
+      *(f4a_t *)(W32 + ro) = y;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) nacc[v] += w[v] * w[v];
+  }
+  block_reduce_columns4<LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
 }
 
 // fp64 panel slot -> fp32 archive slot (the probes, vector 0 of a run)
