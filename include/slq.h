@@ -113,6 +113,17 @@ int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const in
 int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                           const int32_t *d_rowptr, const int32_t *d_colind, const void *d_vals,
                           slq_operator **out);
+/* Gram operator x -> A^T (A x) of a rectangular CSR matrix A (mrows x ncols, host arrays): the operator Lanczos sees is
+ * ncols x ncols (src/primate/include/eigen_operators.h:57-72, SparseEigenLinearOperator<F, true>; unbound in the reference's
+ * Python module, src/primate/_lanczos.cpp:104-111). */
+int slq_csr_gram_create(slq_context *ctx, int dtype, int64_t mrows, int64_t ncols, int64_t nnz, const int32_t *rowptr,
+                        const int32_t *colind, const void *vals, slq_operator **out);
+/* Affine operator A + t B of two n x n CSR matrices (eigen_operators.h:106-137, SparseEigenAffineOperator); t = 0 until
+ * slq_operator_set_parameter (eigen_operators.h:134-136) changes it. Stored on the union pattern as an ordinary CSR operator. */
+int slq_csr_affine_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz_a, const int32_t *rowptr_a, const int32_t *colind_a,
+                          const void *vals_a, int64_t nnz_b, const int32_t *rowptr_b, const int32_t *colind_b, const void *vals_b,
+                          slq_operator **out);
+int slq_operator_set_parameter(slq_operator *op, double t);
 /* Dense symmetric n x n, column-major with leading dimension lda (host array, copied). */
 int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const void *A, int64_t lda,
                      slq_operator **out);

@@ -53,6 +53,9 @@ _SIGNATURES = {
 	"slq_context_device": (C.c_int, [_P, C.POINTER(C.c_int)]),
 	"slq_csr_create": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, _PP]),
 	"slq_csr_create_device": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, _P, _P, _PP]),
+	"slq_csr_gram_create": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _PP]),
+	"slq_csr_affine_create": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _PP]),
+	"slq_operator_set_parameter": (C.c_int, [_P, C.c_double]),
 	"slq_dense_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, C.c_int64, _PP]),
 	"slq_callback_create": (C.c_int, [_P, C.c_int, C.c_int64, MATVEC_FN, _P, _PP]),
 	"slq_operator_destroy": (C.c_int, [_P]),

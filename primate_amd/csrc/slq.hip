@@ -74,7 +74,7 @@ static void ctx_release(slq_context *ctx) {
   if (--ctx->refs == 0 && ctx->dead) ctx_free(ctx);
 }
 
-enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2, OP_DEVICE_CALLBACK = 3 };
+enum { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2, OP_DEVICE_CALLBACK = 3, OP_GRAM = 4 };
 
 struct slq_operator {
   slq_context *ctx;
@@ -97,7 +97,12 @@ struct slq_operator {
   double rms_dist = -1.0;  // rms |i - j| over the stored nonzeros inside an XCD chunk (-1: unknown)
   int64_t nnz_u = 0;       // entries of the upper-triangle copy
   double far_per_row = 0.0;  // stored nonzeros per row with |i - j| > 4096 (0 when unknown: device-resident CSR)
-  void *vals_t = nullptr;    // OP_DENSE, non-symmetric input only: the transpose, for the kernel that walks A by columns (null: A == A^T)
+  // OP_GRAM (x -> A^T (A x), A is mrows x n): rowptr/colind/vals hold A, the *_t arrays its transpose (n rows)
+  int64_t mrows = 0;
+  int32_t *rowptr_t = nullptr, *colind_t = nullptr;
+  // affine CSR operator A + t B (slq_csr_affine_create): values of A and B on the union pattern (vals = va + t vb)
+  void *vals_a = nullptr, *vals_b = nullptr;
+  void *vals_t = nullptr;    // OP_DENSE, non-symmetric input only (also the values of A^T for OP_GRAM): the transpose, for the kernel that walks A by columns (null: A == A^T)
 };
 
 struct ProfEvent {
@@ -138,7 +143,8 @@ struct slq_plan {
   size_t esz;
   int64_t slot_stride;  // elements between ring slots
   void *ring;
-  void *T;              // product panel for dense / callback operators
+  void *T;              // product panel for dense / callback / Gram operators
+  void *T2;             // Gram operator: the intermediate A W_c (mrows rows per panel)
   void *stage;          // column-major staging (probe upload, callback round trips)
   int stage_cols;
   StepState st;
@@ -518,9 +524,19 @@ static bool build_symmetric_upper(int64_t n, const int32_t *rowptr, const int32_
   return true;
 }
 
+// plain != 0: rows stay in the caller's order and no derived copy (upper triangle, tiles) is built - for operators whose
+// values change after creation (the affine operator)
+static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
+                           const void *vals, slq_operator **out, int plain);
+
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
                               slq_operator **out) {
+  return csr_create_impl(ctx, dtype, n, nnz, rowptr, colind, vals, out, 0);
+}
+
+static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
+                           const void *vals, slq_operator **out, int plain) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
   *out = nullptr;
   SLQ_TRY(check_dtype(dtype));
@@ -551,7 +567,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   // 126^3: 8486) whose natural-order halo no longer fits any cache level it is 9-12 % FASTER. Automatic
   // mode therefore reorders only when the rms index distance exceeds 2048 rows AND the permutation cuts
   // it to 60 % or less (random graphs gain nothing and are left alone).
-  const int reorder_mode = env_int("SLQ_REORDER", -1);
+  const int reorder_mode = plain ? 0 : env_int("SLQ_REORDER", -1);
   // rms index distance of the nonzeros whose two ends lie in the same XCD chunk (links that cross
   // chunks are served by another XCD's L2 whatever the order inside the chunks)
   const int64_t rchunk = (n + 7) / 8;
@@ -598,7 +614,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   std::vector<int32_t> tile_row;
   int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool have_tiles = false;
-  if (env_int("SLQ_TILES", 0) != 0 && nnz > 0 && n >= 4096) {
+  if (!plain && env_int("SLQ_TILES", 0) != 0 && nnz > 0 && n >= 4096) {
     std::vector<int32_t> order, inv0;
     if (op->perm_h) {
       inv0.resize((size_t)n);
@@ -686,7 +702,7 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   // scalar q^T A q, so it can run on the upper triangle with doubled off-diagonals and gather half the
   // panel rows. Built only when the stored CSR is EXACTLY symmetric (pattern and values, sorted rows
   // without duplicates); anything else keeps the full rows. SLQ_SYM_ALPHA=0 disables it.
-  if (env_int("SLQ_SYM_ALPHA", 1) != 0 && nnz > 0) {
+  if (!plain && env_int("SLQ_SYM_ALPHA", 1) != 0 && nnz > 0) {
     std::vector<int32_t> urp, uci;
     std::vector<char> uva;
     bool sym = dtype == SLQ_F64 ? build_symmetric_upper<double>(n, rowptr, colind, (const double *)vals, urp, uci, uva)
@@ -778,6 +794,135 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   return SLQ_OK;
 }
 
+// Gram operator x -> A^T (A x) of a rectangular CSR matrix A (mrows x ncols): the symmetric positive semidefinite
+// operator Lanczos sees is ncols x ncols (eigen_operators.h:57-72, SparseEigenLinearOperator<F, true>; what numrank /
+// singular-value functions of a rectangular matrix use). A and its transpose (built here) live on the device; a
+// product is two plain panel SpMMs.
+extern "C" int slq_csr_gram_create(slq_context *ctx, int dtype, int64_t mrows, int64_t ncols, int64_t nnz, const int32_t *rowptr,
+                                   const int32_t *colind, const void *vals, slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (mrows <= 0 || ncols <= 0 || mrows >= (int64_t)1 << 31 || ncols >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31)
+    return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices");
+  if (!rowptr || (nnz > 0 && (!colind || !vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  if (rowptr[0] != 0 || rowptr[mrows] != nnz) return fail(SLQ_EINVAL, "rowptr[0] must be 0 and rowptr[mrows] must equal nnz");
+  for (int64_t i = 0; i < mrows; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(SLQ_EINVAL, "rowptr is not non-decreasing at %lld", (long long)i);
+  for (int64_t q = 0; q < nnz; ++q)
+    if (colind[q] < 0 || colind[q] >= ncols) return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[q], (long long)q);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
+  slq_operator *op = new (std::nothrow) slq_operator();
+  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
+  ctx_retain(ctx);
+  *op = slq_operator{ctx, OP_GRAM, dtype, ncols, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
+  op->mrows = mrows;
+  const size_t es = esize(dtype);
+  // transpose on the host (counting sort by column; rows of A^T come out with ascending indices)
+  std::vector<int32_t> tp((size_t)ncols + 1, 0), tc((size_t)nnz);
+  std::vector<char> tv((size_t)nnz * es);
+  for (int64_t q = 0; q < nnz; ++q) ++tp[(size_t)colind[q] + 1];
+  for (int64_t c = 0; c < ncols; ++c) tp[(size_t)c + 1] += tp[(size_t)c];
+  {
+    std::vector<int32_t> cur(tp.begin(), tp.end() - 1);
+    for (int64_t i = 0; i < mrows; ++i)
+      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+        const int32_t w = cur[(size_t)colind[q]]++;
+        tc[(size_t)w] = (int32_t)i;
+        memcpy(tv.data() + (size_t)w * es, (const char *)vals + (size_t)q * es, es);
+      }
+  }
+  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(mrows + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->rowptr_t, (size_t)(ncols + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind_t, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals_t, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, rowptr, (size_t)(mrows + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, colind, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, vals, (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr_t, tp.data(), (size_t)(ncols + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind_t, tc.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals_t, tv.data(), (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "Gram operator upload: %s", hipGetErrorString(e));
+  }
+  *out = op;
+  return SLQ_OK;
+}
+
+// Affine sparse operator A + t B (eigen_operators.h:106-137, SparseEigenAffineOperator): both n x n CSR. The operator is an
+// ordinary CSR operator on the UNION pattern - every fused pass applies - whose values are va + t vb, recomputed on the
+// device by slq_operator_set_parameter (t = 0 at creation, like the reference's _param).
+extern "C" int slq_csr_affine_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz_a, const int32_t *rp_a, const int32_t *ci_a,
+                                     const void *va, int64_t nnz_b, const int32_t *rp_b, const int32_t *ci_b, const void *vb,
+                                     slq_operator **out) {
+  if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
+  *out = nullptr;
+  SLQ_TRY(check_dtype(dtype));
+  if (n <= 0 || !rp_a || !rp_b || rp_a[0] != 0 || rp_b[0] != 0 || rp_a[n] != nnz_a || rp_b[n] != nnz_b)
+    return fail(SLQ_EINVAL, "bad CSR arrays for the affine operator");
+  const size_t es = esize(dtype);
+  std::vector<int32_t> rp((size_t)n + 1, 0), ci;
+  std::vector<char> ua, ub;
+  std::vector<std::pair<int32_t, int>> a_row, b_row;
+  const char zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < n; ++i) {
+    a_row.clear();
+    b_row.clear();
+    for (int32_t q = rp_a[i]; q < rp_a[i + 1]; ++q) a_row.emplace_back(ci_a[q], q);
+    for (int32_t q = rp_b[i]; q < rp_b[i + 1]; ++q) b_row.emplace_back(ci_b[q], q);
+    std::sort(a_row.begin(), a_row.end());
+    std::sort(b_row.begin(), b_row.end());
+    size_t x = 0, y = 0;
+    while (x < a_row.size() || y < b_row.size()) {
+      const int32_t ca = x < a_row.size() ? a_row[x].first : INT32_MAX, cb = y < b_row.size() ? b_row[y].first : INT32_MAX;
+      const int32_t c = std::min(ca, cb);
+      if (c < 0 || c >= n) return fail(SLQ_EINVAL, "column index out of range in the affine operator");
+      ci.push_back(c);
+      ua.insert(ua.end(), zero, zero + es);
+      ub.insert(ub.end(), zero, zero + es);
+      if (ca == c) { memcpy(ua.data() + ua.size() - es, (const char *)va + (size_t)a_row[x].second * es, es); ++x; }
+      if (cb == c) { memcpy(ub.data() + ub.size() - es, (const char *)vb + (size_t)b_row[y].second * es, es); ++y; }
+    }
+    rp[(size_t)i + 1] = (int32_t)ci.size();
+  }
+  const int64_t nnz = (int64_t)ci.size();
+  // the union pattern with A's values is an ordinary CSR operator; keep its rows as given (no reordering, no upper-triangle
+  // alpha pass: both would have to follow every parameter change)
+  slq_operator *op = nullptr;
+  const int rc = csr_create_impl(ctx, dtype, n, nnz, rp.data(), ci.data(), ua.data(), &op, 1);
+  if (rc != SLQ_OK) return rc;
+  hipError_t e = hipMalloc(&op->vals_a, std::max<size_t>((size_t)nnz * es, 8));
+  if (e == hipSuccess) e = hipMalloc(&op->vals_b, std::max<size_t>((size_t)nnz * es, 8));
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals_a, ua.data(), (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals_b, ub.data(), (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "affine operator upload: %s", hipGetErrorString(e));
+  }
+  *out = op;
+  return SLQ_OK;
+}
+
+// t of an affine operator A + t B (SparseEigenAffineOperator::set_parameter, eigen_operators.h:134-136)
+extern "C" int slq_operator_set_parameter(slq_operator *op, double t) {
+  if (!op) return fail(SLQ_EINVAL, "op is NULL");
+  if (!op->vals_a || !op->vals_b) return fail(SLQ_EINVAL, "not an affine operator");
+  HIP_TRY(hipSetDevice(op->ctx->device));
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (op->nnz + 255) / 256));
+  if (op->dtype == SLQ_F64)
+    k_affine_vals<double><<<grid, 256, 0, op->ctx->stream>>>(op->nnz, (const double *)op->vals_a, (const double *)op->vals_b, t, (double *)op->vals);
+  else
+    k_affine_vals<float><<<grid, 256, 0, op->ctx->stream>>>(op->nnz, (const float *)op->vals_a, (const float *)op->vals_b, t, (float *)op->vals);
+  HIP_TRY(hipGetLastError());
+  return SLQ_OK;
+}
+
 extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const void *A, int64_t lda,
                                 slq_operator **out) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
@@ -865,6 +1010,10 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
     if (op->vals) hipFree(op->vals);
   }
   if (op->vals_t) hipFree(op->vals_t);
+  if (op->rowptr_t) hipFree(op->rowptr_t);
+  if (op->colind_t) hipFree(op->colind_t);
+  if (op->vals_a) hipFree(op->vals_a);
+  if (op->vals_b) hipFree(op->vals_b);
   if (op->perm_d) hipFree(op->perm_d);
   delete op->perm_h;
   if (op->rowptr_u) hipFree(op->rowptr_u);
@@ -1056,6 +1205,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   if (p->ring) hipFree(p->ring);
   if (p->ring32) hipFree(p->ring32);
   if (p->T) hipFree(p->T);
+  if (p->T2) hipFree(p->T2);
   if (p->stage) hipFree(p->stage);
   if (p->scal) hipFree(p->scal);
   if (p->part) hipFree(p->part);
@@ -1180,12 +1330,14 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   }
   const size_t t_slabs = op->kind == OP_CSR ? 0 : (size_t)(1 + p->dense_ks);
   if (e == hipSuccess && t_slabs) e = hipMalloc(&p->T, t_slabs * (size_t)p->slot_stride * p->esz);
+  const size_t t2_bytes = op->kind == OP_GRAM ? (size_t)p->NP * (size_t)op->mrows * p->PW * p->esz : 0;
+  if (e == hipSuccess && t2_bytes) e = hipMalloc(&p->T2, t2_bytes);
   if (e != hipSuccess) {
     slq_plan_destroy(p);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP,
                 "plan workspace (%zu bytes of Lanczos panels): %s", ring_bytes, hipGetErrorString(e));
   }
-  p->bytes = ring_bytes + ring32_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + t_slabs * (size_t)p->slot_stride * p->esz;
+  p->bytes = ring_bytes + ring32_bytes + nscal * 8 + npart * 8 + (bp + 2 * bp * deg) * 8 + t_slabs * (size_t)p->slot_stride * p->esz + t2_bytes;
   double *s = p->scal;
   p->st.alpha = s; s += (size_t)(deg + 1) * bp;
   s += (size_t)orth * bp;  // nu rows for t = -orth .. -1 (zero unless the drop-in entry preloads stale columns)
@@ -1578,6 +1730,19 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
              DISPATCH(p->dtype, p->LPR,
                       (k_dense_panel<F, L><<<g, dim3(kBlock), 0, st>>>(p->n,
                                           (const F *)(op->vals_t ? op->vals_t : op->vals), op->lda, (const F *)slot_ptr(p, slot_c), (F *)p->T))));
+    return SLQ_OK;
+  }
+  if (op->kind == OP_GRAM) {
+    // T = A^T (A W_c): two plain panel SpMMs through an mrows-row panel (eigen_operators.h:66-72, gram = true)
+    const dim3 g1(std::max(1, std::min(p->nblkS, (int)((op->mrows + kWaves - 1) / kWaves))), p->NP), g2(p->nblkS, p->NP);
+    PROFILED(p, SLQ_K_SPMM,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_spmm_plain<F, L><<<g1, dim3(kBlock), 0, st>>>((int)op->mrows, op->rowptr, op->colind, (const F *)op->vals,
+                                                                   (const F *)slot_ptr(p, slot_c), (F *)p->T2, p->n))));
+    PROFILED(p, SLQ_K_SPMM,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_spmm_plain<F, L><<<g2, dim3(kBlock), 0, st>>>(p->n, op->rowptr_t, op->colind_t, (const F *)op->vals_t,
+                                                                   (const F *)p->T2, (F *)p->T, (int)op->mrows))));
     return SLQ_OK;
   }
   if (op->kind == OP_DEVICE_CALLBACK) {
@@ -2512,7 +2677,7 @@ extern "C" int slq_operator_matmat(slq_operator *op, const void *X, int64_t ldx,
       dim3 g(p->nblkS, p->NP);
       DISPATCH(p->dtype, p->LPR,
                (k_spmm_plain<F, L><<<g, dim3(kBlock), 0, st>>>(p->n, op->rowptr, op->colind,
-                                   (const F *)op->vals, (const F *)slot_ptr(p, 0), (F *)slot_ptr(p, 1))));
+                                   (const F *)op->vals, (const F *)slot_ptr(p, 0), (F *)slot_ptr(p, 1), p->n)));
     } else {
       rc = apply_operator_unfused(p, 0);
       if (rc == SLQ_OK) {

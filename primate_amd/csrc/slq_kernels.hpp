@@ -737,18 +737,18 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 }
 
 // ---- plain panel SpMM: Y = A X (operator plugin surface; also the dense/CSR matmat entry) -------
+// (rectangular matrices too - the Gram operator's two passes: n output rows, ncols input rows per panel)
 template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_spmm_plain(int n, const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ colind,
                                                        const F *__restrict__ vals,
-                                                       const F *__restrict__ X, F *__restrict__ Y) {
+                                                       const F *__restrict__ X, F *__restrict__ Y, int ncols) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
-  const int64_t poff = (int64_t)blockIdx.y * n * PW + cl * V;
-  const F *x = X + poff;
-  F *y = Y + poff;
+  const F *x = X + (int64_t)blockIdx.y * ncols * PW + cl * V;
+  F *y = Y + (int64_t)blockIdx.y * n * PW + cl * V;
   const int stride = gridDim.x * kWaves * RPW;
   for (int r0 = (blockIdx.x * kWaves + wave) * RPW; r0 < n; r0 += stride) {
     const int row = r0 + g;
@@ -759,6 +759,12 @@ __global__ __launch_bounds__(kBlock) void k_spmm_plain(int n, const int32_t *__r
       *(VF *)(y + (int64_t)row * PW) = acc;
     }
   }
+}
+
+// Affine sparse operator A + t B on the union pattern: vals = va + t * vb (slq_operator_set_parameter)
+template <typename F> __global__ void k_affine_vals(int64_t nnz, const F *__restrict__ va, const F *__restrict__ vb, double t, F *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (F)((double)va[i] + t * (double)vb[i]);
 }
 
 // Dense symmetric operator, column-major with leading dimension lda: Y[i,:] = sum_k A[k,i] X[k,:]

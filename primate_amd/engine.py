@@ -124,6 +124,30 @@ class DeviceOperator:
 			vals = np.ascontiguousarray(M.data, dtype=self.dtype)
 			check(L.slq_csr_create(self.ctx._h, dt, M.shape[0], M.nnz, ptr(rowptr), ptr(colind), ptr(vals), C.byref(h)))
 			self.kind, self.nnz = "csr", int(M.nnz)
+		elif getattr(A, "_slq_kind", None) == "gram":
+			## x -> B^T (B x) for a rectangular sparse B (primate_amd.operators.GramOperator): slq_csr_gram_create
+			M = sp.csr_matrix(A.A).astype(self.dtype)
+			M.sort_indices()
+			rowptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
+			colind = np.ascontiguousarray(M.indices, dtype=np.int32)
+			vals = np.ascontiguousarray(M.data, dtype=self.dtype)
+			check(L.slq_csr_gram_create(self.ctx._h, dt, M.shape[0], M.shape[1], M.nnz, ptr(rowptr), ptr(colind), ptr(vals), C.byref(h)))
+			self.kind, self.nnz = "gram", int(M.nnz)
+		elif getattr(A, "_slq_kind", None) == "affine":
+			## A + t B (primate_amd.operators.AffineOperator): slq_csr_affine_create; t follows A.set_parameter
+			Ma, Mb = (sp.csr_matrix(Z).astype(self.dtype) for Z in (A.A, A.B))
+			for Z in (Ma, Mb):
+				Z.sort_indices()
+			arrs = [np.ascontiguousarray(Z.indptr, dtype=np.int32) for Z in (Ma, Mb)] + [np.ascontiguousarray(Z.indices, dtype=np.int32) for Z in (Ma, Mb)]
+			va, vb = (np.ascontiguousarray(Z.data, dtype=self.dtype) for Z in (Ma, Mb))
+			check(L.slq_csr_affine_create(self.ctx._h, dt, Ma.shape[0], Ma.nnz, ptr(arrs[0]), ptr(arrs[2]), ptr(va), Mb.nnz, ptr(arrs[1]), ptr(arrs[3]), ptr(vb), C.byref(h)))
+			self.kind, self.nnz = "affine", int(Ma.nnz + Mb.nnz)
+			self._h = h
+			self.set_parameter(getattr(A, "t", 0.0))
+			A._device_ops = getattr(A, "_device_ops", [])
+			import weakref
+
+			A._device_ops.append(weakref.ref(self))
 		elif hasattr(A, "matmat_device"):
 			## GPU-resident plugin: A.matmat_device(X, Y, stream) receives two objects with
 			## `__cuda_array_interface__` (shape (ncols, n), C order = column-major n x ncols) and a stream handle
@@ -164,6 +188,10 @@ class DeviceOperator:
 			check(L.slq_callback_create(self.ctx._h, dt, n, cb, None, C.byref(h)))
 			self.kind, self.nnz = "callback", 0
 		self._h = h
+
+	def set_parameter(self, t: float) -> None:
+		"""t of an affine operator A + t B (SparseEigenAffineOperator::set_parameter, eigen_operators.h:134-136)."""
+		check(_capi.lib().slq_operator_set_parameter(self._h, float(t)))
 
 	def matmat(self, X: np.ndarray) -> np.ndarray:
 		X = np.asfortranarray(X.reshape(self.shape[1], -1), dtype=self.dtype)

@@ -195,6 +195,69 @@ def matrix_function(A, fun: Optional[Callable] = None, v: Optional[np.ndarray] =
 	return M if v is None else M._matvec(v)
 
 
+class GramOperator(LinearOperator):
+	"""x -> A^T (A x) for a rectangular (sparse) A: the symmetric positive semidefinite operator behind the singular
+	values of A (rank by `numrank`, nuclear / Schatten norms by `sqrt` of its spectrum, ...). The reference's native
+	`SparseEigenLinearOperator<F, true>` (src/primate/include/eigen_operators.h:57-72), which its Python module never binds
+	(`_lanczos.cpp:104-111`). On the device it is two panel SpMMs per Lanczos step (`slq_csr_gram_create`); the host
+	methods are the plugin surface of every other operator."""
+
+	_slq_kind = "gram"
+
+	def __init__(self, A, dtype=None):
+		import scipy.sparse as sp
+
+		self.A = sp.csr_matrix(A)
+		self.dtype = np.dtype(dtype if dtype is not None else (self.A.dtype if self.A.dtype in (np.float32, np.float64) else np.float64))
+		self.A = self.A.astype(self.dtype)
+		self.shape = (self.A.shape[1], self.A.shape[1])
+
+	def _matvec(self, x: np.ndarray) -> np.ndarray:
+		return self.A.T @ (self.A @ np.asarray(x).ravel())
+
+	def _matmat(self, X: np.ndarray) -> np.ndarray:
+		return self.A.T @ (self.A @ X)
+
+	def _adjoint(self):
+		return self
+
+
+class AffineOperator(LinearOperator):
+	"""A + t B for two sparse n x n matrices and a scalar t that changes between solves: the reference's native
+	`SparseEigenAffineOperator` (src/primate/include/eigen_operators.h:106-137; unbound in its Python module). On the device
+	both live on their union pattern as ONE CSR operator - every fused pass applies - and `set_parameter(t)` rewrites its
+	values in place (`slq_csr_affine_create`, `slq_operator_set_parameter`), also for operators already wrapped in a
+	`MatrixFunction`."""
+
+	_slq_kind = "affine"
+
+	def __init__(self, A, B, t: float = 0.0, dtype=None):
+		import scipy.sparse as sp
+
+		self.A, self.B = sp.csr_matrix(A), sp.csr_matrix(B)
+		assert self.A.shape == self.B.shape and self.A.shape[0] == self.A.shape[1], "A and B must be square and of equal shape"
+		self.dtype = np.dtype(dtype if dtype is not None else (self.A.dtype if self.A.dtype in (np.float32, np.float64) else np.float64))
+		self.shape = self.A.shape
+		self.t = float(t)
+
+	def set_parameter(self, t: float) -> None:
+		self.t = float(t)
+		for ref in getattr(self, "_device_ops", []):
+			op = ref()
+			if op is not None and getattr(op, "_h", None):
+				op.set_parameter(self.t)
+
+	def _matvec(self, x: np.ndarray) -> np.ndarray:
+		x = np.asarray(x).ravel()
+		return (self.A @ x + self.t * (self.B @ x)).astype(self.dtype, copy=False)
+
+	def _matmat(self, X: np.ndarray) -> np.ndarray:
+		return (self.A @ X + self.t * (self.B @ X)).astype(self.dtype, copy=False)
+
+	def _adjoint(self):
+		return self
+
+
 class Toeplitz(LinearOperator):
 	"""Matrix-free symmetric-or-not Toeplitz operator with first column `c` and first row `r` (default r = c),
 	applied by circulant embedding and two FFTs of length 2n (src/primate/operators.py:165-183). A host-side

@@ -435,6 +435,59 @@ def test_toeplitz_plugin_through_the_callback_operator():
 	np.testing.assert_allclose(M1.quad(X), M2.quad(X), rtol=1e-9)
 
 
+def test_gram_and_affine_sparse_operators(oracle):
+	"""The two native operators of the reference's plugin header that its Python module never binds
+	(eigen_operators.h:57-72 gram = true, :106-137 affine): x -> A^T (A x) for a rectangular sparse A, and A + t B with a
+	parameter that changes after creation. Oracle: the reference recurrence over a Python callback that applies the same
+	product (pylinop.h:32-40), same probes."""
+	import scipy.sparse as sp
+
+	from primate_amd.engine import DeviceOperator, quad_batch
+	from primate_amd.operators import AffineOperator, GramOperator, MatrixFunction
+
+	rng = np.random.default_rng(17)
+	B = sp.random(700, 400, density=0.02, random_state=3, format="csr", dtype=np.float64)
+	G = GramOperator(B)
+	assert G.shape == (400, 400)
+	X = np.asfortranarray(rng.standard_normal((400, 70)))
+	dense = (B.T @ B).toarray()
+
+	class GramPy:  # what the reference's PyLinearOperator would be handed
+		shape, dtype = (400, 400), np.dtype(np.float64)
+
+		def matvec(self, x):
+			return B.T @ (B @ x)
+
+	op = DeviceOperator(G)
+	np.testing.assert_allclose(op.matmat(X), dense @ X, rtol=1e-12, atol=1e-12)
+	for orth in (0, 3, 25):
+		ref = oracle.quad_batch(GramPy(), np.asfortranarray(X[:, :6]), 25, orth, fun="sqrt", fresh_q=True)
+		## (A^T A of a random sparse A has a small-eigenvalue tail that sqrt amplifies: measured 1.5e-9; the bar is 1e-6)
+		np.testing.assert_allclose(quad_batch(op, X, 25, orth, fun="sqrt")[:6], ref, rtol=1e-7, err_msg=f"orth={orth}")
+	## numerical rank of a rectangular matrix of known rank through numrank (special.py:103-105) of its Gram operator:
+	## every probe's Gauss rule counts the same number of eigenvalues above the threshold once k exceeds the rank
+	U, V = rng.standard_normal((300, 12)), rng.standard_normal((12, 200))
+	R = sp.csr_matrix(U @ V)
+	M = MatrixFunction(GramOperator(R), fun="numrank", deg=40, orth=40)
+	q = M.quad(np.asfortranarray(rng.standard_normal((200, 16))))
+	np.testing.assert_allclose(q.mean(), 12.0, rtol=0.35)  # tr step(A^T A) = rank; 16 Gaussian probes: ~25 % standard error
+	## affine: A + t B on the union pattern, t changed in place
+	from conftest import laplacian_2d
+
+	A0 = laplacian_2d(24)
+	n = A0.shape[0]
+	Bm = sp.diags([rng.uniform(0.5, 1.5, n), rng.uniform(-0.2, 0.2, n - 7), rng.uniform(-0.2, 0.2, n - 7)], [0, 7, -7]).tocsr()
+	Bm = ((Bm + Bm.T) * 0.5).tocsr()
+	Aff = AffineOperator(A0, Bm)
+	Mf = MatrixFunction(Aff, fun="log", deg=20, orth=3)
+	Xa = np.asfortranarray(np.floor(rng.random((n, 9)) * 2) * 2 - 1)
+	for t in (0.0, 0.75, -0.25, 0.0):
+		Aff.set_parameter(t)  # reaches the device operator inside Mf
+		ref = oracle.quad_batch((A0 + t * Bm).tocsr(), Xa, 20, 3, fun="log", fresh_q=True)
+		np.testing.assert_allclose(Mf.quad(Xa), ref, rtol=1e-10, err_msg=f"t={t}")
+		np.testing.assert_allclose(Mf._op.matmat(Xa), (A0 + t * Bm) @ Xa, rtol=1e-12, atol=1e-12)
+
+
 def test_torch_plugin_operator_stays_on_the_device():
 	"""A LinearOperator plugin written in torch (GPU tensors in, GPU tensors out) inside the device Lanczos loop:
 	same tridiagonal, quadrature and f(A)v as the dense matrix it wraps; errors raised in the plugin surface."""
