@@ -165,6 +165,7 @@ typedef struct {
   int reordered;     /* rows stored in the XCD-aware reverse Cuthill-McKee order                        */
   int upper_alpha;   /* alpha pass walks the upper triangle (exactly symmetric CSR)                     */
   double far_per_row;/* stored nonzeros per row further than 4096 rows from the diagonal                */
+  int tiles;         /* fused passes run on LDS workgroup tiles: 0 no, 1 behind barriers, 2 ring-fed (SLQ_TILES) */
 } slq_plan_info;
 int slq_plan_describe(const slq_plan *plan, slq_plan_info *out);
 

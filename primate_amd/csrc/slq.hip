@@ -89,6 +89,9 @@ struct slq_operator {
   int32_t *perm_d;               // device: stored row i = caller row perm[i]; null if not reordered
   std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
   TileMeta tiles;                // workgroup LDS tiles of the fused passes (tile_ptr == null: none; SLQ_TILES)
+  bool tiles_ringed = false;     // ... built to the caps of k_csr_ring_pass (SLQ_TILES=2), which reads these two:
+  int32_t *tile_desc = nullptr;  // 64 words per tile
+  char *tile_rec = nullptr;      // the tiles' CSR records
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
@@ -155,6 +158,7 @@ struct slq_plan {
   size_t alpha_pad;                // LDS padding that caps its residency
   double *quad_d, *nodes_d, *weights_d;
   int *fail_d;
+  int *ring_fail_d;
   int rmax;
   bool probes_ready, ran;
   int pdf_sphere;
@@ -176,12 +180,18 @@ struct slq_plan {
   int dense_ks;               // dense MFMA operator with big tiles: K split over this many workgroups per row tile (0: 16-row kernel)
 };
 
-constexpr double kTileMaxColsPerRow = 4.0;  // tiles are kept when a tile row needs at most this many distinct panel rows
+// SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
+// loader waves (k_csr_ring_pass). Read when an operator is created (the rows are regrouped into the tiles) and when a plan
+// is created (whether its passes use them).
+constexpr int kTilesDefault = 2;
+constexpr double kTileMaxColsPerRow = 4.0;      // tiles are kept when a tile row needs at most this many distinct panel rows
+constexpr double kTileAutoMaxColsPerRow = 3.0;  // ... when nobody asked for tiles (SLQ_TILES unset)
 
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
 }
+static int tiles_mode() { return env_int("SLQ_TILES", kTilesDefault); }
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -386,8 +396,10 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
 static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *colind, const int32_t *order_in, const int32_t *inv_in,
                            std::vector<int32_t> &order_out, std::vector<int32_t> &tile_row, int32_t xcd_tile[9]) {
   const int64_t chunk = (n + 7) / 8;
-  const int tmax = std::max(1, std::min(env_int("SLQ_TILE_ROWS", kTileRows), 64));
-  const int dcap = std::max(8, std::min(env_int("SLQ_TILE_COLS", kTileCols), kTileCols));
+  const bool ringed = tiles_mode() == 2;  // tiles of the ring-fed kernel (k_csr_ring_pass): smaller, fixed caps
+  const int tmax = ringed ? kRingTileRows : std::max(1, std::min(env_int("SLQ_TILE_ROWS", kTileRows), 64));
+  const int dcap = ringed ? kRingTileCols : std::max(8, std::min(env_int("SLQ_TILE_COLS", kTileCols), kTileCols));
+  const int nzcap = ringed ? kRingTileNnz : std::numeric_limits<int>::max();  // the ring kernel's tile record is bounded
   std::vector<char> assigned((size_t)n, 0);
   std::vector<int32_t> stamp((size_t)n, -1);
   struct Cand { int32_t node, cnt, disc; };
@@ -406,7 +418,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
     for (int64_t b = lo; b < hi; ++b) {
       const int32_t seed = order_in ? order_in[b] : (int32_t)b;
       if (assigned[(size_t)seed]) continue;
-      int D = 0, ndisc = 0;
+      int D = 0, ndisc = 0, nz = 0;
       cand.clear();
       const size_t first_member = order_out.size();
       auto new_cols = [&](int32_t v) {
@@ -417,6 +429,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
       auto add = [&](int32_t v) {
         assigned[(size_t)v] = 1;
         order_out.push_back(v);
+        nz += rowptr[v + 1] - rowptr[v];
         if (stamp[(size_t)v] != cid) { stamp[(size_t)v] = cid; ++D; }
         for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) {
           const int32_t c = colind[p];
@@ -428,7 +441,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
           }
         }
       };
-      if (new_cols(seed) > dcap) return false;
+      if (new_cols(seed) > dcap || rowptr[seed + 1] - rowptr[seed] > nzcap) return false;
       add(seed);
       while ((int)(order_out.size() - first_member) < tmax && !cand.empty()) {
         size_t best = 0;
@@ -438,7 +451,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
         cand[best] = cand.back();
         cand.pop_back();
         if (assigned[(size_t)v]) continue;
-        if (D + new_cols(v) > dcap) continue;  // would not fit the image: leave it for a later cluster
+        if (D + new_cols(v) > dcap || nz + rowptr[v + 1] - rowptr[v] > nzcap) continue;  // would not fit: leave it for a later cluster
         add(v);
       }
       tile_row.push_back((int32_t)order_out.size());
@@ -482,6 +495,39 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
   }
   tile_cols.insert(tile_cols.end(), kCsrPad, 0);
   *max_cols = mx;
+}
+
+// What k_csr_ring_pass reads (SLQ_TILES=2; layouts in slq_kernels.hpp): per tile a 64-word descriptor and a record of its
+// CSR in the tile's own numbering, every record at a 16-byte boundary of one blob that ends in a spare record's worth of
+// zeros (a record is fetched in whole KiB).
+template <typename F>
+static void build_ring_stream(const int32_t *rowptr, const F *vals, const std::vector<int32_t> &tile_row, const std::vector<int32_t> &tile_ptr,
+                              const std::vector<int32_t> &tile_cols, const std::vector<int32_t> &lcol, const std::vector<int32_t> &self_idx,
+                              std::vector<int32_t> &desc, std::vector<char> &rec) {
+  const size_t ntiles = tile_row.size() - 1;
+  desc.assign(ntiles * 64, 0);
+  rec.clear();
+  for (size_t t = 0; t < ntiles; ++t) {
+    const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
+    const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
+    const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = kRecHeadBytes + nzp * 4, bytes = (valoff + nzp * sizeof(F) + 15) / 16 * 16;
+    const size_t off = rec.size();
+    rec.resize(off + bytes, 0);
+    int32_t *head = (int32_t *)(rec.data() + off);
+    for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
+    head[kRecValOff] = (int32_t)valoff;
+    for (int32_t i = 0; i < rows; ++i) head[kRecSelf + i] = self_idx[(size_t)(r0 + i)];
+    memcpy(rec.data() + off + kRecHeadBytes, lcol.data() + p0, (size_t)nz * 4);
+    memcpy(rec.data() + off + valoff, vals + p0, (size_t)nz * sizeof(F));
+    int32_t *d = desc.data() + t * 64;
+    d[kDescCols] = D;
+    d[kDescRecOff] = (int32_t)(off / 16);
+    d[kDescRecChunks] = (int32_t)((bytes + 1023) / 1024);
+    d[kDescRow0] = r0;
+    d[kDescRows] = rows;
+    for (int32_t c = 0; c < D; ++c) d[kDescList + c] = tile_cols[(size_t)tile_ptr[t] + c];
+  }
+  rec.resize(rec.size() + kRingMetaBytes, 0);
 }
 
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
@@ -586,8 +632,66 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     }
     return std::sqrt(acc / (double)std::max<int64_t>(cnt, 1));
   };
+  // Workgroup tiles (SLQ_TILES, tiles_mode()): the rows are regrouped into compact clusters = the tiles of k_csr_tile_pass /
+  // k_csr_ring_pass, on top of a base order. Kept only if the tiles actually share rows: distinct panel rows per tile row
+  // at most kTileMaxColsPerRow when SLQ_TILES is set, kTileAutoMaxColsPerRow by default (5-point grid: 2.1-2.4, kept; 7-point
+  // grid: 3.9 with the ring kernel's 36-row images, declined by default - measured a wash; random graph: 10+).
+  const int tmode = plain ? 0 : tiles_mode();
+  const bool tiles_forced = getenv("SLQ_TILES") != nullptr;
+  const bool try_tiles = tmode != 0 && nnz > 0 && n >= (tiles_forced ? 4096 : 65536);
+  const double tile_limit = tiles_forced ? kTileMaxColsPerRow : kTileAutoMaxColsPerRow;
+  std::vector<int32_t> tile_row;
+  int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool have_tiles = false;
+  // clusters on top of `base` (stored row -> caller row; null: the caller's order); on success `order` is the new order
+  auto cluster_tiles = [&](const std::vector<int32_t> *base, std::vector<int32_t> &order) -> bool {
+    std::vector<int32_t> inv0;
+    if (base) {
+      inv0.resize((size_t)n);
+      for (int64_t i = 0; i < n; ++i) inv0[(size_t)(*base)[(size_t)i]] = (int32_t)i;
+    }
+    if (!build_clusters(n, rowptr, colind, base ? base->data() : nullptr, base ? inv0.data() : nullptr, order, tile_row, xcd_tile)) return false;
+    // distinct indices per tile row, on the caller's numbering (the exact lists are built below)
+    int64_t dsum = 0;
+    std::vector<int32_t> stamp((size_t)n, -1);
+    for (size_t t = 0; t + 1 < tile_row.size(); ++t)
+      for (int32_t q = tile_row[t]; q < tile_row[t + 1]; ++q) {
+        const int32_t v = order[(size_t)q];
+        if (stamp[(size_t)v] != (int32_t)t) { stamp[(size_t)v] = (int32_t)t; ++dsum; }
+        for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp)
+          if (stamp[(size_t)colind[pp]] != (int32_t)t) { stamp[(size_t)colind[pp]] = (int32_t)t; ++dsum; }
+      }
+    const double per_row = (double)dsum / (double)n;
+    if (env_int("SLQ_DEBUG", 0) != 0)
+      fprintf(stderr, "[slq] tiles: %zu clusters, %.2f rows each, %.2f distinct panel rows per row (limit %.1f)\n", tile_row.size() - 1,
+              (double)n / (double)(tile_row.size() - 1), per_row, tile_limit);
+    return per_row <= tile_limit;
+  };
+  auto adopt = [&](std::vector<int32_t> &order) -> bool {
+    if (!op->perm_h) op->perm_h = new (std::nothrow) std::vector<int32_t>();
+    if (!op->perm_h) return false;
+    op->perm_h->swap(order);
+    return true;
+  };
+  std::vector<int32_t> rcm_perm;  // the in-chunk Cuthill-McKee order, computed at most once
+  auto rcm_order = [&]() -> const std::vector<int32_t> & {
+    if (rcm_perm.empty()) xcd_rcm_permutation(n, rowptr, colind, rcm_perm);
+    return rcm_perm;
+  };
+  // Ring-fed tiles sweep a chunk tile after tile, 32 CUs abreast, and re-read a neighbour tile's rows from L2 only if the
+  // neighbour is at most a few dozen tiles away: the BASE order must have short level sets, whatever the index distances
+  // are. On the 2-D grid of configs[1] in its natural order (grid rows of 1000 = 270 tiles) every vertical neighbour was
+  // fetched again (7.5 GB per dots pass against 6.3 algorithmic); on the in-chunk Cuthill-McKee order (levels of <= 125
+  // nodes = 34 tiles) the pass fetches 6.37 GB. So mode 2 clusters the Cuthill-McKee order unless SLQ_REORDER=0 forbids it.
+  if (try_tiles && tmode == 2 && reorder_mode != 0) {
+    std::vector<int32_t> order;
+    if (cluster_tiles(&rcm_order(), order)) {
+      have_tiles = true;
+      if (!adopt(order)) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+    }
+  }
   bool want = false;
-  if (nnz > 0) {
+  if (nnz > 0 && !have_tiles) {
     if (reorder_mode == 2) want = true;
     else if (reorder_mode == 1) want = n >= 65536;
     else if (reorder_mode < 0) want = n >= 65536 && mean_dist(nullptr) > 2048.0;
@@ -596,7 +700,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     op->perm_h = new (std::nothrow) std::vector<int32_t>();
     if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
     std::vector<int32_t> &perm = *op->perm_h;
-    xcd_rcm_permutation(n, rowptr, colind, perm);
+    perm = rcm_order();
     std::vector<int32_t> inv((size_t)n);
     for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
     const double d_new = mean_dist(&inv);
@@ -607,42 +711,20 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       op->rms_dist = d_new;
     }
   }
-  if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
-  // SLQ_TILES (opt-in): regroup the rows into compact clusters = workgroup tiles of k_csr_tile_pass, on top of whatever
-  // order was chosen above. Kept only if the tiles actually share rows: on average at most kTileMaxColsPerRow distinct
-  // panel rows per tile row (a 7-point grid reaches 3.0, a 5-point grid 1.7; a random graph 10+ and keeps the generic path).
-  std::vector<int32_t> tile_row;
-  int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  bool have_tiles = false;
-  if (!plain && env_int("SLQ_TILES", 0) != 0 && nnz > 0 && n >= 4096) {
-    std::vector<int32_t> order, inv0;
-    if (op->perm_h) {
-      inv0.resize((size_t)n);
-      for (int64_t i = 0; i < n; ++i) inv0[(size_t)(*op->perm_h)[(size_t)i]] = (int32_t)i;
-    }
-    if (build_clusters(n, rowptr, colind, op->perm_h ? op->perm_h->data() : nullptr, op->perm_h ? inv0.data() : nullptr, order, tile_row, xcd_tile)) {
-      // distinct indices per tile row, estimated on the caller's numbering (exact lists are built below)
-      int64_t dsum = 0;
-      std::vector<int32_t> stamp((size_t)n, -1);
-      for (size_t t = 0; t + 1 < tile_row.size(); ++t)
-        for (int32_t q = tile_row[t]; q < tile_row[t + 1]; ++q) {
-          const int32_t v = order[(size_t)q];
-          if (stamp[(size_t)v] != (int32_t)t) { stamp[(size_t)v] = (int32_t)t; ++dsum; }
-          for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp)
-            if (stamp[(size_t)colind[pp]] != (int32_t)t) { stamp[(size_t)colind[pp]] = (int32_t)t; ++dsum; }
-        }
-      const double per_row = (double)dsum / (double)n;
-      if (env_int("SLQ_DEBUG", 0) != 0)
-        fprintf(stderr, "[slq] tiles: %zu clusters, %.2f rows each, %.2f distinct panel rows per row\n", tile_row.size() - 1,
-                (double)n / (double)(tile_row.size() - 1), per_row);
-      if (per_row <= kTileMaxColsPerRow) {
-        have_tiles = true;
-        if (!op->perm_h) op->perm_h = new (std::nothrow) std::vector<int32_t>();
-        if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
-        op->perm_h->swap(order);
-      }
+  // tiles on top of whatever order was chosen above: mode 1, and mode 2 when SLQ_REORDER=0 kept it from its own base order
+  if (try_tiles && !have_tiles && (tmode == 1 || reorder_mode == 0)) {
+    std::vector<int32_t> order;
+    if (cluster_tiles(op->perm_h, order)) {
+      have_tiles = true;
+      if (!adopt(order)) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
     }
   }
+  if (have_tiles) {
+    std::vector<int32_t> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)(*op->perm_h)[(size_t)i]] = (int32_t)i;
+    op->rms_dist = mean_dist(&inv);
+  }
+  if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
   if (op->perm_h) {
     std::vector<int32_t> &perm = *op->perm_h;
     std::vector<int32_t> inv((size_t)n);
@@ -749,6 +831,17 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     op->tiles.self_idx = d_si;
     for (int x = 0; x < 9; ++x) op->tiles.xcd_tile[x] = xcd_tile[x];
     op->tiles.max_cols = mx;
+    op->tiles_ringed = tiles_mode() == 2;
+    if (te == hipSuccess && op->tiles_ringed) {
+      std::vector<int32_t> desc;
+      std::vector<char> rec;
+      if (dtype == SLQ_F64) build_ring_stream<double>(rowptr, (const double *)vals, tile_row, tp, tc, lc, si, desc, rec);
+      else build_ring_stream<float>(rowptr, (const float *)vals, tile_row, tp, tc, lc, si, desc, rec);
+      te = hipMalloc((void **)&op->tile_desc, desc.size() * 4);
+      if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec, rec.size());
+      if (te == hipSuccess) te = hipMemcpy(op->tile_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
+      if (te == hipSuccess) te = hipMemcpy(op->tile_rec, rec.data(), rec.size(), hipMemcpyHostToDevice);
+    }
     if (te != hipSuccess) {
       slq_operator_destroy(op);
       return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile upload: %s", hipGetErrorString(te));
@@ -1024,6 +1117,8 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->tiles.tile_cols) hipFree((void *)op->tiles.tile_cols);
   if (op->tiles.lcol) hipFree((void *)op->tiles.lcol);
   if (op->tiles.self_idx) hipFree((void *)op->tiles.self_idx);
+  if (op->tile_desc) hipFree(op->tile_desc);
+  if (op->tile_rec) hipFree(op->tile_rec);
   ctx_release(op->ctx);
   delete op;
   return SLQ_OK;
@@ -1241,7 +1336,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->esz = esize(op->dtype);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   env_int("SLQ_TILES", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   tiles_mode() != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
@@ -1290,8 +1385,9 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
     // per CU and panel in the grid, panel after panel
     const int img_kib = op->tiles.tile_ptr ? (op->tiles.max_cols + 16) * (SLQ_TILE_DB ? 2 : 1) : 160;
-    const int per_cu_t = std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", std::max(1, std::min(4, 160 / std::max(img_kib, 1)))));
+    const int per_cu_t = op->tiles_ringed ? 1 : std::max(1, env_int("SLQ_BLOCKS_PER_CU_TILED", std::max(1, std::min(4, 160 / std::max(img_kib, 1)))));
     int per_xcd_t = std::max(1, ctx->num_cus * per_cu_t / 8);
+    per_xcd_t = std::max(1, std::min(per_xcd_t, env_int("SLQ_TILED_WGS_PER_XCD", per_xcd_t)));  // (experiments: fewer CUs sweeping a chunk)
     if (op->tiles.tile_ptr) {
       int mn = 1 << 30;
       for (int x = 0; x < 8; ++x) mn = std::min(mn, std::max(1, op->tiles.xcd_tile[x + 1] - op->tiles.xcd_tile[x]));
@@ -1349,6 +1445,11 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->st.gamma = s;
   p->st.steps = p->st.active + bp;
   p->fail_d = p->st.steps + bp;
+  p->ring_fail_d = p->fail_d + 1;  // raised by k_csr_ring_pass when a bounded spin ran out (never cleared: the plan is dead)
+  if (hipMemset(p->ring_fail_d, 0, sizeof(int)) != hipSuccess) {
+    slq_plan_destroy(p);
+    return fail(SLQ_EHIP, "hipMemset failed");
+  }
   p->st.bpad = p->bpad;
   p->st.nprobes = nprobes;
   p->st.deg = deg;
@@ -1501,6 +1602,16 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
 #undef TILE_RC
     for (const void *fn : tiled_fns)
       if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    std::vector<const void *> ring_fns = {
+        (const void *)k_csr_ring_pass<F, PASS_ALPHA, 0, 0>, (const void *)k_csr_ring_pass<F, PASS_ALPHA, 1, 0>,
+        (const void *)k_csr_ring_pass<F, PASS_UPDATE, 0, 0>, (const void *)k_csr_ring_pass<F, PASS_UPDATE, 1, 0>,
+#define RING_RC(R)                                                                                              \
+  (const void *)k_csr_ring_pass<F, PASS_ADOTS, 0, R>, (const void *)k_csr_ring_pass<F, PASS_ADOTS, 1, R>,       \
+      (const void *)k_csr_ring_pass<F, PASS_UPDATE, 0, R>, (const void *)k_csr_ring_pass<F, PASS_UPDATE, 1, R>
+        RING_RC(1), RING_RC(2), RING_RC(3)};
+#undef RING_RC
+    for (const void *fn : ring_fns)
+      if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   return e;
 }
@@ -1516,13 +1627,16 @@ static int set_kernel_attributes(slq_plan *p) {
   return SLQ_OK;
 }
 
+// the plan's fused passes run on the operator's workgroup tiles: wide panels (one row per wave) of an operator that has them
+static bool plan_tiled(const slq_plan *p) { return p->LPR == 64 && p->op->tiles.tile_ptr != nullptr && p->sw.tiles; }
+
 // which launch sequence the steps with r <= kFusedMaxR take (enqueue_run): 0 sweeps, 1 recompute passes, 2 stored u
 static int plan_sequence(const slq_plan *p) {
   const slq_operator *op = p->op;
   if (p->ring32_on) return 3;
   if (op->kind != OP_CSR || p->sw.fused == 0 || p->sw.mgs || p->nstale > 0) return 0;
   if (p->sw.fused == 2 || op->far_per_row <= 4.0) return 1;
-  return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !p->sw.tiles) ? 2 : 0;
+  return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !plan_tiled(p)) ? 2 : 0;
 }
 
 extern "C" int slq_plan_describe(const slq_plan *p, slq_plan_info *out) {
@@ -1535,6 +1649,7 @@ extern "C" int slq_plan_describe(const slq_plan *p, slq_plan_info *out) {
   out->reordered = p->op->perm_d ? 1 : 0;
   out->upper_alpha = p->op->rowptr_u ? 1 : 0;
   out->far_per_row = p->op->far_per_row;
+  out->tiles = plan_tiled(p) ? (p->op->tiles_ringed ? 2 : 1) : 0;
   return SLQ_OK;
 }
 
@@ -1846,6 +1961,15 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
     const slq_operator *op = p->op;
     TileRanges xr;
     for (int x = 0; x < 9; ++x) xr.first[x] = op->tiles.xcd_tile[x];
+    if constexpr (RC <= kRingMaxR) {
+      if (op->tiles_ringed) {
+        // the ring-fed variant: flag words and descriptor staging + kRingSlots slots; 16 waves per workgroup
+        const size_t lds_ring = kRingHeadBytes + (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes);
+        k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, op->tile_desc, op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
+                                                                               p->st.coefB, p->st.gamma, p->part, p->bpad, xt, p->ring_fail_d);
+        return;
+      }
+    }
     k_csr_tile_pass<F, PASS, LP, RC><<<grid, dim3(kBlock), lds, st>>>(p->n, op->rowptr, (const F *)op->vals, op->tiles.tile_row, op->tiles.tile_ptr,
                                                                     op->tiles.tile_cols, op->tiles.lcol, op->tiles.self_idx, xr, op->tiles.max_cols, (F *)p->ring,
                                                                     p->slot_stride, p->S, j, p->st.coefA, p->st.coefB, p->st.gamma, p->part, p->bpad, xt);
@@ -1890,18 +2014,21 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     // ... with r >= 1 the merged pass can store u for the update pass to read back (SLQ_STORED_U, default on):
     // one gather pass per step, 7 reads + 2 writes instead of the sweeps' 9 reads + 3 writes
     const bool stored_u = op->kind == OP_CSR && fused && !gathers_cached && r >= 1 && r <= kFusedMaxR && !mgs &&
-                          p->sw.stored_u && p->sw.merged && !p->sw.tiles;
+                          p->sw.stored_u && p->sw.merged && !plan_tiled(p);
     if (op->kind == OP_CSR && fused && (gathers_cached || stored_u) && r <= kFusedMaxR && !mgs) {
       // ---- fused passes: recompute the SpMM, write once (slq_kernels.hpp: k_csr_pass) ----
       const int V = p->dtype == SLQ_F64 ? 2 : 4;
       const size_t lds0 = sizeof(double) * kWaves * 64 * V;
       // wide panels (one row per wave) of an operator with workgroup tiles (SLQ_TILES): the tile's distinct panel rows are
       // staged once in LDS (k_csr_tile_pass); everything else about the sequence is the same
-      const bool tiled = p->LPR == 64 && op->tiles.tile_ptr != nullptr && p->sw.tiles && !stored_u;
+      // (ring-sized tiles serve up to kRingMaxR ring columns; steps with more take the generic passes, on the same row order)
+      const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR);
       const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
+      // the alpha-only pass of a symmetric operator stays on the upper triangle (half the gathers) rather than the ring
+      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr);
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   do {                                                                                               \
-    if (tiled)                                                                                       \
+    if (tl)                                                                                          \
       DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS, LP, RCT>(p, gT, lds0 + lds_tile, st, j, XT))); \
     else                                                                                             \
       DISPATCH(p->dtype, p->LPR,                                                                     \
@@ -1912,7 +2039,8 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   } while (0)
 #define CSR_PASS(PASS, LP, SP, I0, RC, LDS, XT)                                                        \
   do {                                                                                               \
-    const bool half = !tiled && PASS == PASS_ALPHA && op->rowptr_u != nullptr;                       \
+    const bool tl = PASS == PASS_ALPHA ? alpha_tiled : tiled;                                        \
+    const bool half = !tl && PASS == PASS_ALPHA && op->rowptr_u != nullptr;                          \
     switch (PASS == PASS_ALPHA ? 0 : (RC)) {                                                         \
       case 0: CSR_PASS_RC(PASS, LP, ((PASS == PASS_DOTS || PASS == PASS_ADOTS) ? 1 : 0), LDS, XT); break; \
       case 1: CSR_PASS_RC(PASS, LP, (PASS == PASS_ALPHA ? 0 : 1), LDS, XT); break;                   \
@@ -1926,7 +2054,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     }                                                                                                \
   } while (0)
       // alpha pass: grid and residency cap (nblkF, alpha_pad) are chosen in slq_plan_create
-      const size_t ldsA = lds0 + (tiled ? 0 : p->alpha_pad);
+      const size_t ldsA = lds0 + (alpha_tiled ? 0 : p->alpha_pad);
       // dots/update passes: 64 KiB of LDS padding pins residency at 2 workgroups per CU whatever the variant's
       // register count (62-96 VGPRs would admit 3 for some). Their grid is 2 per CU *per panel*: blocks are
       // dispatched panel-major, so panel 0 fills the chip, panel 1 follows as its workgroups retire, and an
@@ -1948,7 +2076,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       } else {
       PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xt_a); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xt_a); });
       PROFILED(p, SLQ_K_FINALIZE,
-               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, tiled ? p->nblkT : p->nblkF, j, xt_a));
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, alpha_tiled ? p->nblkT : p->nblkF, j, xt_a));
       if (r > 0) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_DOTS, 1, 1, 0, r, lds0 + fused_pad, 0); else CSR_PASS(PASS_DOTS, 0, 0, 0, r, lds0 + fused_pad, 0); });
         PROFILED(p, SLQ_K_FINALIZE,
@@ -2098,7 +2226,10 @@ extern "C" int slq_plan_get_tridiag(slq_plan *p, void *alpha, void *beta, int32_
   HIP_TRY(hipMemcpyAsync(ha.data(), p->st.alpha, ha.size() * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(hn.data(), p->st.nu, hn.size() * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(hs.data(), p->st.steps, (size_t)bp * 4, hipMemcpyDeviceToHost, st));
+  int ring_bad = 0;
+  HIP_TRY(hipMemcpyAsync(&ring_bad, p->ring_fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (ring_bad) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
   for (int i = 0; i < P; ++i) {
     for (int t = 0; t <= deg; ++t) {
       const double a = ha[(size_t)t * bp + i];
@@ -2134,12 +2265,14 @@ extern "C" int slq_plan_quadrature(slq_plan *p, int fun_id, const double *fun_pa
            hipLaunchKernelGGL(k_quadrature, dim3((P + lanes - 1) / lanes), dim3(64), lds, st, p->st, lanes, fun_id, p0, p1,
                               p->quad_d, (nodes ? p->nodes_d : nullptr), (weights ? p->weights_d : nullptr), p->fail_d));
   HIP_TRY(hipGetLastError());
-  int bad = 0;
-  HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
+  int bad2[2] = {0, 0};  // fail_d, ring_fail_d
+  HIP_TRY(hipMemcpyAsync(bad2, p->fail_d, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   if (quad) HIP_TRY(hipMemcpyAsync(quad, p->quad_d, (size_t)P * 8, hipMemcpyDeviceToHost, st));
   if (nodes) HIP_TRY(hipMemcpyAsync(nodes, p->nodes_d, (size_t)P * deg * 8, hipMemcpyDeviceToHost, st));
   if (weights) HIP_TRY(hipMemcpyAsync(weights, p->weights_d, (size_t)P * deg * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  const int bad = bad2[0];
+  if (bad2[1]) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
   if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
   return SLQ_OK;
 }

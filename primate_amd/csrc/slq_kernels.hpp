@@ -736,6 +736,337 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
   }
 }
 
+// ---- the tiled passes with a continuously fed ring of tile images (opt-in, SLQ_TILES=2) -----------------------------
+// k_csr_tile_pass alternates "land a tile, barrier, compute it, barrier": a CU's memory pipe is idle half the time, and
+// every wave walks the CSR with dependent scalar loads. Here the workgroup (one per CU, kRingWaves = 16 waves) splits into
+// kRingLoaders LOADER waves and the rest CONSUMER waves around a ring of kRingSlots slots in LDS, and EVERYTHING a tile needs arrives
+// in its slot by LDS-DMA: the image (its distinct panel rows, 1 KiB each) and a RECORD of its CSR (row offsets, the
+// position of every row's own line, per nonzero the line of its column and the value - see RingRecord below).
+//  * every tile has a 256-byte DESCRIPTOR (tile_desc, 64 ints: counts, where its record and rows start, its distinct
+//    panel rows) that one wave reads with ONE coalesced load, two tiles ahead, so no scalar-memory round trip sits
+//    between tiles (scalar loads share lgkmcnt with LDS and return out of order: one in flight turns every LDS wait into
+//    a wait for memory);
+//  * a loader, per tile k: loads descriptor k + 1; waits with ONE counted s_waitcnt vmcnt(N) (N = its DMAs of tile k - 1
+//    plus that load) - which says both "descriptor k is here" and "tile k - 2 has landed"; publishes tile k - 2
+//    (ready[slot] += 1); waits until the consumers have released slot k % kRingSlots (done[slot]); issues its share of
+//    tile k's DMAs. Two tiles of DMAs per loader stay in flight throughout;
+//  * a consumer wave prefetches the row-local streams (W_p, ring columns) of its rows of tile k + 1 into registers, polls
+//    ready[slot(k)] in LDS, computes its rows of tile k out of the slot (CSR entries fetched by lanes 0-7 and broadcast
+//    with v_readlane), and releases the slot (done[slot] += 1).
+// Nothing but these LDS counters synchronises the waves inside the loop; every poll is bounded (kRingSpinMax, then the
+// workgroup raises *fail and leaves: the host reports the run as failed instead of hanging the GPU).
+#ifndef SLQ_RING_LOADERS
+#define SLQ_RING_LOADERS 2
+#endif
+#ifndef SLQ_RING_SLOTS
+#define SLQ_RING_SLOTS 4
+#endif
+#ifndef SLQ_RING_AUX
+#define SLQ_RING_AUX 0  // cache policy of the image DMAs (1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef SLQ_RING_WAVES
+#define SLQ_RING_WAVES 16
+#endif
+#ifndef SLQ_RING_ROWS
+#define SLQ_RING_ROWS 14
+#endif
+#ifndef SLQ_RING_COLS
+#define SLQ_RING_COLS 36
+#endif
+constexpr int kRingWaves = SLQ_RING_WAVES;  // a consumer's work per row is a chain of LDS latencies: many consumer waves hide it
+constexpr int kRingBlock = kRingWaves * 64;
+constexpr int kRingLoaders = SLQ_RING_LOADERS;
+constexpr int kRingSlots = SLQ_RING_SLOTS;
+constexpr int kRingLag = 2;                   // a loader's tiles in flight (fixed by the schedule above)
+constexpr int kRingTileRows = SLQ_RING_ROWS;  // one row per consumer wave
+constexpr int kRingTileCols = SLQ_RING_COLS;  // distinct panel rows per tile at most
+constexpr int kRingTileNnz = 160;             // nonzeros per tile at most: the record fits kRingMetaBytes in fp64
+constexpr int kRingMetaBytes = 2048;          // 4 slots x (36 + 2) KiB + kRingHeadBytes = 156 KiB
+constexpr int kRingHeadBytes = 4096;          // flag words + the loaders' descriptor staging
+constexpr int kRingSpinMax = 1 << 20;         // ~0.1 s of polling
+constexpr int kRingMaxR = 3;                  // ring columns per step served (more: 128 VGPRs at 16 waves do not hold the sums)
+// descriptor words (tile_desc[t * 64 + ...])
+constexpr int kDescCols = 0, kDescRecOff = 1, kDescRecChunks = 2, kDescRow0 = 3, kDescRows = 4, kDescList = 8;
+// record words: [0 .. rows] row offsets into the record's own nonzeros, [15] byte offset of the values,
+// [16 .. 16 + rows) line of each row's own panel row, then from byte 128 the column lines (int32) and the values (F)
+constexpr int kRecValOff = 15, kRecSelf = 16, kRecHeadBytes = 128;
+static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders <= 3 && kRingTileRows <= 15 && kRingTileCols <= 64 - kDescList, "ring geometry");
+static_assert(kRingWaves <= 16 && (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes) + kRingHeadBytes <= 160 * 1024, "ring slots must fit the LDS");
+static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes), "the final reduction reuses the slots");
+static_assert(kRecHeadBytes + ((kRingTileNnz + 3) / 4 * 4) * (4 + 8) <= kRingMetaBytes, "a tile's record must fit its slot");
+static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + 2) * kRingLag + 1 <= 56, "a loader's DMAs in flight are counted by vmcnt");
+
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {
+#define SLQ_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : n) {
+    SLQ_VM(0) SLQ_VM(1) SLQ_VM(2) SLQ_VM(3) SLQ_VM(4) SLQ_VM(5) SLQ_VM(6) SLQ_VM(7) SLQ_VM(8) SLQ_VM(9) SLQ_VM(10) SLQ_VM(11)
+    SLQ_VM(12) SLQ_VM(13) SLQ_VM(14) SLQ_VM(15) SLQ_VM(16) SLQ_VM(17) SLQ_VM(18) SLQ_VM(19) SLQ_VM(20) SLQ_VM(21) SLQ_VM(22)
+    SLQ_VM(23) SLQ_VM(24) SLQ_VM(25) SLQ_VM(26) SLQ_VM(27) SLQ_VM(28) SLQ_VM(29) SLQ_VM(30) SLQ_VM(31) SLQ_VM(32) SLQ_VM(33)
+    SLQ_VM(34) SLQ_VM(35) SLQ_VM(36) SLQ_VM(37) SLQ_VM(38) SLQ_VM(39) SLQ_VM(40) SLQ_VM(41) SLQ_VM(42) SLQ_VM(43) SLQ_VM(44)
+    SLQ_VM(45) SLQ_VM(46) SLQ_VM(47) SLQ_VM(48) SLQ_VM(49) SLQ_VM(50) SLQ_VM(51) SLQ_VM(52) SLQ_VM(53) SLQ_VM(54) SLQ_VM(55)
+    default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;  // a stricter wait than asked for is always safe
+  }
+#undef SLQ_VM
+}
+
+// broadcast lane `l` (wave-uniform) of a value held one entry per lane
+__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename F, int PASS, int NTP, int RC>
+__global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
+    int n, const int32_t *__restrict__ tile_desc, const char *__restrict__ tile_rec, TileRanges xr, F *ring, int64_t slot_stride, int S, int j,
+    const double *__restrict__ coefA, const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
+    int bpad, int xt, int *__restrict__ fail) {
+  using VF = typename VecT<F>::type;
+  constexpr int LPR = 64;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
+  constexpr int NX = RC > 2 ? RC - 2 : 1;
+  constexpr int NC = kRingWaves - kRingLoaders;      // consumer waves
+  constexpr int MR = (kRingTileRows + NC - 1) / NC;  // rows of a tile per consumer wave
+  constexpr int kSlotBytes = kRingTileCols * 1024 + kRingMetaBytes;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // ready[kRingSlots], done[kRingSlots], abort. Explicit LDS pointers: a generic one would make every poll a flat load
+  // that waits on vmcnt too - on the loader's own DMAs
+  using lds_int = __attribute__((address_space(3))) int;
+  lds_int *flags = (lds_int *)lds_raw;
+  unsigned char *slots = lds_raw + kRingHeadBytes;
+  double *red = (double *)slots;  // the final reduction (kRingWaves*64*V doubles) runs when the slots are dead
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int panel = blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + lane * V;
+  xt &= 1;
+  const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
+  const F *wcl = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
+  F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *ux[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) ux[i] = ring + (int64_t)ring_slot(j - 2 - i, S) * slot_stride + poff;
+  if (threadIdx.x < 2 * kRingSlots + 1) flags[threadIdx.x] = 0;  // (ordinary store, before the barrier)
+  __syncthreads();
+  lds_int *ready = flags, *done = flags + kRingSlots, *abort_f = flags + 2 * kRingSlots;
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
+  const int t_first = xr.first[xcd] + bl, t_end = xr.first[xcd + 1];
+  const int ntiles = t_first < t_end ? (t_end - t_first + nbl - 1) / nbl : 0;
+  VF acc1 = (VF)(F)0, accx = (VF)(F)0;
+  VF dacc[RC > 0 ? RC : 1], gacc[RC > 0 ? RC : 1];
+#pragma unroll
+  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = gacc[i] = (VF)(F)0;
+  // Bounded LDS poll: until *w >= want; false when the workgroup is aborting. Polls and counter updates are written in
+  // assembly: a compiler-visible LDS access in the loader would be preceded by s_waitcnt vmcnt(0) (the compiler orders LDS
+  // accesses after every outstanding LDS-DMA), draining exactly the DMAs meant to stay in flight. The orderings that
+  // matter are explicit instead: the loader's counted vmcnt wait before it publishes, the consumer's lgkmcnt(0) before it
+  // releases.
+  auto spin = [&](lds_int *w, int want) -> bool {
+    for (int it = 0; it < kRingSpinMax; ++it) {
+      int have, ab;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(have), "=&v"(ab)
+                   : "v"((unsigned)(uintptr_t)w), "v"((unsigned)(uintptr_t)abort_f)
+                   : "memory");
+      if (__builtin_amdgcn_readfirstlane(have) >= want) return true;
+      if (__builtin_amdgcn_readfirstlane(ab)) return false;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(abort_f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) *fail = 1;
+    return false;
+  };
+  auto bump = [&](lds_int *w) { asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)w), "v"(1) : "memory"); };
+  // descriptor of the k-th tile of this workgroup, one word per lane (tiles past the end: the last one again, unused)
+  auto load_desc = [&](int k) -> int { return tile_desc[(int64_t)(t_first + min(k, ntiles - 1) * nbl) * 64 + lane]; };
+  if (ntiles > 0 && wave < kRingLoaders) {
+    // ---------------- loader ----------------
+    // Descriptors reach the loader through LDS as well (a 256-byte DMA into a small staging ring, read back with an
+    // assembly ds_read after the counted wait): a descriptor loaded into a register across the DMA loop would make the
+    // compiler drain vmcnt to 0 at every use, and with it the DMAs meant to stay in flight.
+    unsigned char *stage = lds_raw + 256 + (size_t)wave * 4 * 256;  // 4 descriptors per loader, after the flag words
+    auto stage_desc = [&](int k) {
+      const int32_t *src = tile_desc + (int64_t)(t_first + min(k, ntiles - 1) * nbl) * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(stage + (k & 3) * 256), 4, 0, 0);
+    };
+    stage_desc(0);
+    int issued_prev = 0;
+    bool ok = true;
+    for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
+      stage_desc(k + 1);
+      // descriptor k is here and tile k - 2 has landed once only tile k - 1's DMAs and the one above are outstanding
+      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(issued_prev + 1));
+      if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % kRingSlots);
+      int issued = 0;
+      if (k < ntiles) {
+        const int slot = k % kRingSlots;
+        int dcur;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dcur) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + (k & 3) * 256) + lane * 4) : "memory");
+        if (k >= kRingSlots) ok = spin(done + slot, NC * (k / kRingSlots));  // the slot's previous tile has been consumed
+        if (ok) {
+          unsigned char *img = slots + (size_t)slot * kSlotBytes;
+          const int D = lane_bcast(dcur, kDescCols);
+          for (int d = wave; d < D; d += kRingLoaders) {
+            const int col = lane_bcast(dcur, kDescList + d);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)col * PW),
+                                             (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
+            ++issued;
+          }
+          // the record, 1 KiB per DMA, by the loaders in turn
+          const int chunks = lane_bcast(dcur, kDescRecChunks);
+          const char *rsrc = tile_rec + (int64_t)lane_bcast(dcur, kDescRecOff) * 16 + lane * 16;
+          for (int c = wave; c < chunks; c += kRingLoaders) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
+                                             (__attribute__((address_space(3))) void *)(img + kRingTileCols * 1024 + c * 1024), 16, 0, 0);
+            ++issued;
+          }
+        }
+      }
+      issued_prev = issued;
+    }
+  } else if (ntiles > 0) {
+    // ---------------- consumer ----------------
+    const int cw = wave - kRingLoaders;
+    const int colbase = panel * PW + lane * V;
+    VF sc, cp, cb = (VF)(F)0;
+    VF gm[RC > 0 ? RC : 1];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sc[v] = (F)coefA[colbase + v];
+      cp[v] = (F)coefA[bpad + colbase + v];
+      if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
+    }
+    if (PASS == PASS_UPDATE) {
+#pragma unroll
+      for (int i = 0; i < RC; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) gm[i][v] = (F)gamma[(int64_t)i * bpad + colbase + v];
+    }
+    VF xpn[MR], un[MR][NX];
+    auto fetch_rows = [&](int r_lo, int nrows) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int lr = cw + i * NC;
+        if (lr < nrows) {
+          const int64_t ro = (int64_t)(r_lo + lr) * PW;
+          if (!first) xpn[i] = stream_load<NTP>((const VF *)(wp + ro));
+          if (PASS != PASS_ALPHA && RC > 2) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) un[i][q] = stream_load<NTP>((const VF *)(ux[q] + ro));
+          }
+        }
+      }
+    };
+    int dcur = load_desc(0), dnext = load_desc(1);
+    fetch_rows(lane_bcast(dcur, kDescRow0), lane_bcast(dcur, kDescRows));
+    bool ok = true;
+    for (int k = 0; k < ntiles && ok; ++k) {
+      const int slot = k % kRingSlots;
+      const int r_lo = lane_bcast(dcur, kDescRow0), nrows = lane_bcast(dcur, kDescRows);
+      const int dnext2 = load_desc(k + 2);
+      VF xpc[MR], uc[MR][NX];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        xpc[i] = xpn[i];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) uc[i][q] = un[i][q];
+      }
+      if (k + 1 < ntiles) fetch_rows(lane_bcast(dnext, kDescRow0), lane_bcast(dnext, kDescRows));
+      ok = spin(ready + slot, kRingLoaders * (k / kRingSlots + 1));
+      if (!ok) break;
+      const unsigned char *img = slots + (size_t)slot * kSlotBytes;
+      const F *xl = (const F *)img + lane * V;
+      const unsigned char *rec = img + kRingTileCols * 1024;
+      const int head = ((const int *)rec)[lane & 31];  // row offsets and own-line positions, one word per lane
+      const int valoff = lane_bcast(head, kRecValOff);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int lr = cw + i * NC;
+        if (lr >= nrows) break;
+        const int64_t ro = (int64_t)(r_lo + lr) * PW;
+        const int p0 = lane_bcast(head, lr), p1 = lane_bcast(head, lr + 1), si = lane_bcast(head, kRecSelf + lr);
+        const VF xp = first ? (VF)(F)0 : xpc[i];
+        const VF xc = *(const VF *)(xl + (size_t)si * PW);
+        VF acc = (VF)(F)0;
+        for (int pb = p0; pb < p1; pb += 8) {
+          const int cnt = p1 - pb;
+          // lanes 0-7 fetch the entries, v_readlane broadcasts them; entries past the row's end read the row's own image
+          // line with a zero coefficient, so the eight image reads go out back to back
+          const int e = min(pb + (lane & 7), p1 - 1);
+          const int lcv = *(const int *)(rec + kRecHeadBytes + e * 4);
+          const F vav = *(const F *)(rec + valoff + e * (int)sizeof(F));
+          VF x[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) x[q] = *(const VF *)(xl + (size_t)(q < cnt ? lane_bcast(lcv, q) : si) * PW);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += (q < cnt ? lane_bcast(vav, q) : (F)0) * x[q];
+        }
+        VF w = sc * acc;
+        if (!first) w -= cp * xp;
+        if (PASS == PASS_ALPHA) {
+          acc1 += (sc * xc) * w;
+        } else if (PASS == PASS_ADOTS) {
+          acc1 += (sc * xc) * w;
+          if constexpr (RC > 1) {
+            dacc[1] += xp * w;
+            gacc[1] += xp * xc;
+          }
+#pragma unroll
+          for (int q = 2; q < RC; ++q) {
+            dacc[q] += uc[i][q - 2] * w;
+            gacc[q] += uc[i][q - 2] * xc;
+          }
+        } else {
+          w -= cb * xc;
+          if constexpr (RC > 0) w -= gm[0] * xc;
+          if constexpr (RC > 1) w -= gm[1] * xp;
+#pragma unroll
+          for (int q = 2; q < RC; ++q) w -= gm[q] * uc[i][q - 2];
+          stream_store<NTP>((VF *)(wn + ro), w);
+          acc1 += w * w;
+          accx += w * xc;
+        }
+      }
+      // every LDS read of this wave from the slot has returned before the release
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) bump(done + slot);
+      dcur = dnext;
+      dnext = dnext2;
+    }
+  }
+  __syncthreads();
+  // partial sums of the consumer waves, column by column in wave order (loaders hold zeros)
+  const int64_t nblk = gridDim.x;
+  auto reduce_out = [&](const VF &a, double *out) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[(wave * 64 + lane) * V + v] = (double)a[v];
+    __syncthreads();
+    if ((int)threadIdx.x < PW) {
+      const int t = threadIdx.x, cl = t / V, v = t % V;
+      double sum = 0.0;
+      for (int w = 0; w < kRingWaves; ++w) sum += red[(w * 64 + cl) * V + v];
+      out[t] = sum;
+    }
+    __syncthreads();
+  };
+  if (PASS == PASS_ADOTS) {
+    reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
+#pragma unroll
+    for (int i = 1; i < RC; ++i) {
+      reduce_out(dacc[i], part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+      reduce_out(gacc[i], part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
+    }
+  } else {
+    reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
+    if (PASS == PASS_UPDATE && xt) reduce_out(accx, part + (nblk + blockIdx.x) * bpad + panel * PW);
+  }
+}
+
 // ---- plain panel SpMM: Y = A X (operator plugin surface; also the dense/CSR matmat entry) -------
 // (rectangular matrices too - the Gram operator's two passes: n output rows, ncols input rows per panel)
 template <typename F, int LPR>

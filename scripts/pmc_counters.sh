@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: bash scripts/pmc_counters.sh <tag> "<pass1 counters>;<pass2 counters>;..." <bench args...>
+# (PMC_SCRIPT="<script.py> <args>" profiles another python script instead of bench.py)
 # one rocprofv3 --pmc pass per ';'-separated group (kernel-trace only, per the pool's rules); prints the
 # per-kernel average of every counter over the launches of the run.
 set -eo pipefail
@@ -11,7 +12,7 @@ IFS=';' read -ra GROUPS_ <<< "$PASSES"
 i=0
 for g in "${GROUPS_[@]}"; do
   i=$((i+1))
-  rocprofv3 --output-format csv --kernel-trace --pmc $g -d $OUT/pass$i -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/log_pass$i.txt || { echo "pass $i ($g) failed"; tail -5 $OUT/log_pass$i.txt; }
+  rocprofv3 --output-format csv --kernel-trace --pmc $g -d $OUT/pass$i -o run -- python3 ${PMC_SCRIPT:-$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline} "$@" > /dev/null 2> $OUT/log_pass$i.txt || { echo "pass $i ($g) failed"; tail -5 $OUT/log_pass$i.txt; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
@@ -28,7 +29,7 @@ for k, d in acc.items():
     res[k]["launches"] = n
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("launches", 0)):
-    if "k_csr_pass" in k or "k_spmm" in k or "k_reorth" in k or "k_axpy" in k:
+    if "k_csr_" in k or "k_spmm" in k or "k_reorth" in k or "k_axpy" in k:
         print(k[:64], " ".join(f"{c}={v:.4g}" for c, v in d.items()))
 PY
 find $OUT -name "*.db" -delete; find $OUT -name "*_kernel_trace.csv" -delete

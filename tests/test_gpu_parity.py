@@ -613,13 +613,30 @@ def test_opt_in_fp32_archive_ring(oracle, eng, monkeypatch):
 	assert eng.LanczosPlan(op, 70, 40, 40).describe()["sequence"] != "sweeps_ring32"
 
 
-def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch, variant):
 	"""SLQ_TILES=1: rows regrouped into compact clusters, every cluster one workgroup tile whose distinct panel rows are
-	staged once in LDS (k_csr_tile_pass). Same per-probe values as the oracle for every ring-column count of the fused
-	steps, both dtypes, 2-D and 3-D grids (with the XCD reordering on top), tile heights 24 / 16 / 7, a matrix with empty
-	rows; operators whose tiles would share nothing keep the generic passes."""
+	staged once in LDS (k_csr_tile_pass); SLQ_TILES=2: the same tiles fed through a ring of LDS images by loader waves
+	(k_csr_ring_pass, ring-column counts up to 3; the rest take k_csr_tile_pass on the same tiles). Same per-probe values
+	as the oracle for every ring-column count of the fused steps, both dtypes, 2-D and 3-D grids (with the XCD reordering
+	on top), tile heights 24 / 16 / 7, a matrix with empty rows; operators whose tiles would share nothing keep the
+	generic passes."""
 	rng = np.random.default_rng(9)
-	monkeypatch.setenv("SLQ_TILES", "1")
+	monkeypatch.setenv("SLQ_TILES", variant)
+	if variant == "2":
+		## enough tiles per workgroup (13 and 21) that every slot of the ring is reused several times
+		for A, P, tol in ((laplacian_2d(200), 130, 1e-10), (laplacian_3d(40), 130, 1e-10), (laplacian_3d(40).astype(np.float32), 300, 3e-4)):
+			n = A.shape[0]
+			X = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1).astype(A.dtype)
+			cols = [0, 64, P - 1]
+			op = eng.DeviceOperator(A)
+			plan = eng.LanczosPlan(op, P, 12, 3)
+			assert plan.describe()["tiles"] == 2
+			plan.close()
+			for o in (0, 3, 5):  # 5: steps with more than 3 ring columns take the generic passes on the tiles' row order
+				ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, o, fun="log", fresh_q=True)
+				np.testing.assert_allclose(eng.quad_batch(op, X, 12, o, fun="log")[cols], ref, rtol=tol, err_msg=f"ring n={n} {A.dtype} orth={o}")
+			op.close()
 	cases = [(laplacian_2d(70), "24", "0"), (laplacian_3d(17), "16", "2"), (laplacian_2d(66), "7", "0")]
 	for A, tr, reorder in cases:
 		monkeypatch.setenv("SLQ_TILE_ROWS", tr)
@@ -630,6 +647,7 @@ def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch):
 		op = eng.DeviceOperator(A)
 		plan = eng.LanczosPlan(op, 130, 14, 3)
 		assert plan.describe()["reordered"] == 1  # the clusters are a row order of their own
+		assert plan.describe()["tiles"] == int(variant)
 		plan.close()
 		for o in (0, 1, 2, 3, 5, 8):
 			ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, o, fun="log", fresh_q=True)
