@@ -2025,7 +2025,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR);
       const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
       // the alpha-only pass of a symmetric operator stays on the upper triangle (half the gathers) rather than the ring
-      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr);
+      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr && env_int("SLQ_RING_ALPHA", 0) == 0);
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   do {                                                                                               \
     if (tl)                                                                                          \

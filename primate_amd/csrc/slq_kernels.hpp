@@ -746,10 +746,10 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 //    panel rows) that one wave reads with ONE coalesced load, two tiles ahead, so no scalar-memory round trip sits
 //    between tiles (scalar loads share lgkmcnt with LDS and return out of order: one in flight turns every LDS wait into
 //    a wait for memory);
-//  * a loader, per tile k: loads descriptor k + 1; waits with ONE counted s_waitcnt vmcnt(N) (N = its DMAs of tile k - 1
-//    plus that load) - which says both "descriptor k is here" and "tile k - 2 has landed"; publishes tile k - 2
-//    (ready[slot] += 1); waits until the consumers have released slot k % kRingSlots (done[slot]); issues its share of
-//    tile k's DMAs. Two tiles of DMAs per loader stay in flight throughout;
+//  * a loader, per tile k: requests descriptor k + kRingLag - 1; waits with ONE counted s_waitcnt vmcnt(N) (N = its DMAs
+//    of the kRingLag - 1 tiles before k plus the descriptor requests since descriptor k's) - which says both "descriptor k is here" and "tile k - kRingLag has
+//    landed"; publishes that tile (ready[slot] += 1); waits until the consumers have released slot k % kRingSlots
+//    (done[slot]); issues its share of tile k's DMAs. kRingLag tiles of DMAs per loader stay in flight throughout;
 //  * a consumer wave prefetches the row-local streams (W_p, ring columns) of its rows of tile k + 1 into registers, polls
 //    ready[slot(k)] in LDS, computes its rows of tile k out of the slot (CSR entries fetched by lanes 0-7 and broadcast
 //    with v_readlane), and releases the slot (done[slot] += 1).
@@ -764,6 +764,9 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 #ifndef SLQ_RING_AUX
 #define SLQ_RING_AUX 0  // cache policy of the image DMAs (1 sc0, 2 nt, 16 sc1)
 #endif
+#ifndef SLQ_RING_LAG
+#define SLQ_RING_LAG 2
+#endif
 #ifndef SLQ_RING_WAVES
 #define SLQ_RING_WAVES 16
 #endif
@@ -777,7 +780,7 @@ constexpr int kRingWaves = SLQ_RING_WAVES;  // a consumer's work per row is a ch
 constexpr int kRingBlock = kRingWaves * 64;
 constexpr int kRingLoaders = SLQ_RING_LOADERS;
 constexpr int kRingSlots = SLQ_RING_SLOTS;
-constexpr int kRingLag = 2;                   // a loader's tiles in flight (fixed by the schedule above)
+constexpr int kRingLag = SLQ_RING_LAG;        // a loader's tiles in flight
 constexpr int kRingTileRows = SLQ_RING_ROWS;  // one row per consumer wave
 constexpr int kRingTileCols = SLQ_RING_COLS;  // distinct panel rows per tile at most
 constexpr int kRingTileNnz = 160;             // nonzeros per tile at most: the record fits kRingMetaBytes in fp64
@@ -794,7 +797,7 @@ static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders
 static_assert(kRingWaves <= 16 && (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes) + kRingHeadBytes <= 160 * 1024, "ring slots must fit the LDS");
 static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes), "the final reduction reuses the slots");
 static_assert(kRecHeadBytes + ((kRingTileNnz + 3) / 4 * 4) * (4 + 8) <= kRingMetaBytes, "a tile's record must fit its slot");
-static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + 2) * kRingLag + 1 <= 56, "a loader's DMAs in flight are counted by vmcnt");
+static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + 2) * kRingLag + 1 <= 63, "a loader's DMAs in flight are counted by vmcnt");
 
 // s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
 __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
@@ -894,13 +897,23 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(stage + (k & 3) * 256), 4, 0, 0);
     };
-    stage_desc(0);
-    int issued_prev = 0;
+    // descriptor k is requested kRingLag - 1 iterations before it is used, i.e. BEFORE the DMAs of tile k - kRingLag + 1:
+    // everything issued after it is then exactly what the counted wait below leaves outstanding
+    static_assert(kRingLag >= 2 && kRingLag <= 4, "the descriptor staging ring holds 4");
+#pragma unroll
+    for (int i = 0; i < kRingLag - 1; ++i) stage_desc(i);
+    int hist[kRingLag - 1];  // DMAs issued for tiles k - 1, k - 2, ... (the ones that may still be in flight)
+#pragma unroll
+    for (int i = 0; i < kRingLag - 1; ++i) hist[i] = 0;
     bool ok = true;
     for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
-      stage_desc(k + 1);
-      // descriptor k is here and tile k - 2 has landed once only tile k - 1's DMAs and the one above are outstanding
-      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(issued_prev + 1));
+      stage_desc(k + kRingLag - 1);
+      // descriptor k is here and tile k - kRingLag has landed once only what was issued after descriptor k is outstanding:
+      // the DMAs of tiles k - kRingLag + 1 .. k - 1 and the kRingLag - 1 descriptor requests since
+      int since = kRingLag - 1;
+#pragma unroll
+      for (int i = 0; i < kRingLag - 1; ++i) since += hist[i];
+      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
       if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % kRingSlots);
       int issued = 0;
       if (k < ntiles) {
@@ -927,7 +940,9 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
           }
         }
       }
-      issued_prev = issued;
+#pragma unroll
+      for (int i = kRingLag - 2; i > 0; --i) hist[i] = hist[i - 1];
+      hist[0] = issued;
     }
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------

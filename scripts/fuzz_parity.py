@@ -1,7 +1,9 @@
 """Randomised parity sweep on the GPU box: random SPD graphs / grids, every panel geometry, orth 0..deg,
 both dtypes, against the CPU oracle on identical probes. Prints one line per failure and a summary.
-usage: python scripts/fuzz_parity.py [seconds] [seed]"""
-import sys, time
+usage: python scripts/fuzz_parity.py [seconds] [seed] [tiles]
+`tiles`: operators big enough for workgroup tiles (n 4,100-45,000, SLQ_TILES=2 forced), wide panels only - the ring-fed
+tile kernels with ragged tile counts, short last tiles, empty and long rows."""
+import os, sys, time
 from pathlib import Path
 import numpy as np, scipy.sparse as sp
 ROOT = Path(__file__).resolve().parent.parent
@@ -13,6 +15,10 @@ from primate_amd import engine as eng
 oracle.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+TILES = len(sys.argv) > 3 and sys.argv[3] == "tiles"
+if TILES:
+	os.environ["SLQ_TILES"] = "2"
+tiled_cases = 0
 
 def random_spd(n, deg, rng):
 	m = int(n * deg / 2)
@@ -28,7 +34,22 @@ illposed_skipped = sensitive_skipped = 0
 worst = 0.0
 while time.time() - t0 < budget:
 	kind = rng.integers(0, 4)
-	if kind == 0:
+	if TILES:
+		if kind == 0:
+			A = laplacian_2d(int(rng.integers(65, 210)))
+		elif kind == 1:
+			A = laplacian_3d(int(rng.integers(17, 35)))
+		elif kind == 2:  # banded with random gaps: rows of 1-9 nonzeros, some empty off-diagonals
+			n0 = int(rng.integers(4100, 45000))
+			offs = np.unique(rng.integers(1, 40, int(rng.integers(1, 5))))
+			S = sp.diags([-rng.uniform(0.0, 1.0, n0 - o) * (rng.random(n0 - o) < 0.8) for o in offs], offs, shape=(n0, n0))
+			S = (S + S.T).tocsr()
+			A = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + rng.uniform(0.05, 1.0, n0))).tocsr()
+			A.eliminate_zeros()
+			A.sort_indices()
+		else:
+			A = random_spd(int(rng.integers(4100, 20000)), float(rng.uniform(1.0, 3.0)), rng)
+	elif kind == 0:
 		A = laplacian_2d(int(rng.integers(6, 60)))
 	elif kind == 1:
 		A = laplacian_3d(int(rng.integers(4, 14)))
@@ -37,7 +58,9 @@ while time.time() - t0 < budget:
 	n = A.shape[0]
 	dtype = np.float64 if rng.random() < 0.7 else np.float32
 	P = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 257]))
-	deg = int(rng.integers(1, min(n, 40) + 1))
+	if TILES:
+		P = int(rng.choice([128, 129, 200, 257])) if dtype == np.float64 else int(rng.choice([256, 257, 300]))
+	deg = int(rng.integers(1, min(n, 20 if TILES else 40) + 1))
 	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, deg]))
 	fun, kw = [("log", {}), ("exp", {"t": -0.1}), ("identity", {}), ("sqrt", {}), ("inv", {})][int(rng.integers(0, 5))]
 	Ad = A.astype(dtype)
@@ -50,6 +73,10 @@ while time.time() - t0 < budget:
 		continue
 	try:
 		op = eng.DeviceOperator(Ad)
+		if TILES:
+			pl = eng.LanczosPlan(op, P, deg, orth)
+			tiled_cases += pl.describe()["tiles"] == 2
+			pl.close()
 		got = eng.quad_batch(op, X, deg, orth, fun=fun, **kw)
 		ref = oracle.quad_batch(Ad, X, deg, orth, fun=fun, fresh_q=True, prefer="csr", **kw)
 		op.close()
@@ -103,5 +130,7 @@ while time.time() - t0 < budget:
 		print(f"FAIL kind={kind} n={n} nnz={A.nnz} dtype={dtype.__name__} P={P} deg={deg} orth={orth} fun={fun} err={err}", flush=True)
 	if cases % 50 == 0:
 		print(f"... {cases} cases, {fails} failures, worst fp64 rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+if TILES:
+	print(f"{tiled_cases} of the {cases} cases ran on ring-fed tiles")
 print(f"done: {cases} cases, {fails} failures ({illposed_skipped} mismatches confined to near-breakdown probes and {sensitive_skipped} within 10x the oracle's own 1-ulp sensitivity not counted), worst fp64 rel err {worst:.2e}")
 sys.exit(1 if fails else 0)
