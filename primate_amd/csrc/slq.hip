@@ -123,7 +123,8 @@ struct Switches {
   int stored_u;    // SLQ_STORED_U  non-local operators: merged pass stores u, update pass reads it back
   int merged;      // SLQ_MERGED    alpha from the merged alpha+dots pass
   int cross;       // SLQ_CROSS     q_c.q_p from the update pass's cross term
-  int tiles;       // SLQ_TILES     experimental LDS row tiles
+  int tiles;       // SLQ_TILES     fused passes on the operator's LDS workgroup tiles (when it has them)
+  int ring_alpha;  // SLQ_RING_ALPHA the alpha-only pass through the ring too, even where the upper triangle is available
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
@@ -132,7 +133,7 @@ struct Switches {
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -184,8 +185,8 @@ struct slq_plan {
 // loader waves (k_csr_ring_pass). Read when an operator is created (the rows are regrouped into the tiles) and when a plan
 // is created (whether its passes use them).
 constexpr int kTilesDefault = 2;
-constexpr double kTileMaxColsPerRow = 4.0;      // tiles are kept when a tile row needs at most this many distinct panel rows
-constexpr double kTileAutoMaxColsPerRow = 3.0;  // ... when nobody asked for tiles (SLQ_TILES unset)
+constexpr double kTileMaxColsPerRow = 4.5;      // tiles are kept when a tile row needs at most this many distinct panel rows
+constexpr double kTileLevelRows = 320.0;        // level sets the tile sweep's base order should not exceed (csr_create_impl)
 
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
@@ -295,8 +296,12 @@ static int check_dtype(int dtype) {
 // bandwidth to the chunk's short dimension (125 for that grid; build/rcm_test in round 1). perm[new] = old.
 // MEASURED RESULT: slower, see slq_csr_create. The L2 behaviour of this kernel is not explained by
 // the reuse-distance model above (fewer resident workgroups also fetch MORE, not less).
-static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm) {
+// sub: second-level pieces per chunk (below). avg_level: if not null, receives the mean size of the breadth-first level sets of
+// the final order - what a tile sweep has to keep in L2 between a row and its neighbours in the next level.
+static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm, int sub,
+                                double *avg_level) {
   perm.resize((size_t)n);
+  int64_t levels = 0, levelled = 0;  // of the committed searches since the last reset
   const int64_t chunk = (n + 7) / 8;
   // Reverse Cuthill-McKee of the subgraph induced by `members` (all with part[v] == id), appended to `out`.
   std::vector<int32_t> deg((size_t)n), part((size_t)n, -1), nbrs, order;
@@ -320,6 +325,10 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       while (head < order.size()) {
         const size_t level_end = order.size();
         level_begin = head;
+        if (commit) {
+          ++levels;
+          levelled += (int64_t)(level_end - head);
+        }
         for (; head < level_end; ++head) {
           const int32_t u = order[head];
           nbrs.clear();
@@ -357,7 +366,8 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
   // BFS levels, i.e. slices ACROSS the chunk's longest direction - and each piece is reordered on its own. A piece is
   // short along the old sweep direction, so its own Cuthill-McKee levels run along another one and are K times
   // smaller: the gather halo an XCD's L2 has to hold shrinks accordingly, at the price of the edges cut between pieces.
-  const int sub = std::max(1, env_int("SLQ_RCM_SUB", 1));
+  sub = std::max(1, sub);
+  int64_t levels_all = 0, levelled_all = 0;
   std::vector<int32_t> members, first, piece, second;
   for (int x = 0; x < 8; ++x) {
     const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
@@ -368,9 +378,11 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       part[(size_t)i] = x;
     }
     first.clear();
+    levels = levelled = 0;
     rcm(members, x, first);
     if (sub > 1 && (int64_t)first.size() >= 64 * sub) {
       second.clear();
+      levels = levelled = 0;
       const size_t len = (first.size() + sub - 1) / sub;
       for (int k = 0; k < sub; ++k) {
         const size_t b0 = std::min(first.size(), k * len), b1 = std::min(first.size(), b0 + len);
@@ -381,8 +393,11 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       }
       first.swap(second);
     }
+    levels_all += levels;
+    levelled_all += levelled;
     for (int64_t q = 0; q < hi - lo; ++q) perm[(size_t)(lo + q)] = first[(size_t)q];
   }
+  if (avg_level) *avg_level = levels_all > 0 ? (double)levelled_all / (double)levels_all : 0.0;
 }
 
 
@@ -633,13 +648,13 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     return std::sqrt(acc / (double)std::max<int64_t>(cnt, 1));
   };
   // Workgroup tiles (SLQ_TILES, tiles_mode()): the rows are regrouped into compact clusters = the tiles of k_csr_tile_pass /
-  // k_csr_ring_pass, on top of a base order. Kept only if the tiles actually share rows: distinct panel rows per tile row
-  // at most kTileMaxColsPerRow when SLQ_TILES is set, kTileAutoMaxColsPerRow by default (5-point grid: 2.1-2.4, kept; 7-point
-  // grid: 3.9 with the ring kernel's 36-row images, declined by default - measured a wash; random graph: 10+).
+  // k_csr_ring_pass, on top of a base order. Kept only if the tiles actually share rows: at most kTileMaxColsPerRow distinct
+  // panel rows per tile row (5-point grid: 2.1, 7-point grid: 3.9 with the ring kernel's 36-row images, random graph: 10+).
+  // Unasked (SLQ_TILES unset) only operators of 65536 rows and more are tried - below that a pass is launch-bound anyway.
   const int tmode = plain ? 0 : tiles_mode();
   const bool tiles_forced = getenv("SLQ_TILES") != nullptr;
   const bool try_tiles = tmode != 0 && nnz > 0 && n >= (tiles_forced ? 4096 : 65536);
-  const double tile_limit = tiles_forced ? kTileMaxColsPerRow : kTileAutoMaxColsPerRow;
+  const double tile_limit = kTileMaxColsPerRow;
   std::vector<int32_t> tile_row;
   int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool have_tiles = false;
@@ -674,8 +689,9 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     return true;
   };
   std::vector<int32_t> rcm_perm;  // the in-chunk Cuthill-McKee order, computed at most once
+  const int sub_env = env_int("SLQ_RCM_SUB", 0);  // 0: 1 piece, except for the tile sweep below
   auto rcm_order = [&]() -> const std::vector<int32_t> & {
-    if (rcm_perm.empty()) xcd_rcm_permutation(n, rowptr, colind, rcm_perm);
+    if (rcm_perm.empty()) xcd_rcm_permutation(n, rowptr, colind, rcm_perm, std::max(1, sub_env), nullptr);
     return rcm_perm;
   };
   // Ring-fed tiles sweep a chunk tile after tile, 32 CUs abreast, and re-read a neighbour tile's rows from L2 only if the
@@ -683,11 +699,25 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   // are. On the 2-D grid of configs[1] in its natural order (grid rows of 1000 = 270 tiles) every vertical neighbour was
   // fetched again (7.5 GB per dots pass against 6.3 algorithmic); on the in-chunk Cuthill-McKee order (levels of <= 125
   // nodes = 34 tiles) the pass fetches 6.37 GB. So mode 2 clusters the Cuthill-McKee order unless SLQ_REORDER=0 forbids it.
+  // ... and level sets no longer than about one round of the sweep (32 CUs x 10 rows): a 12.5-plane slab of a 100^3 grid has
+  // level sets of 590 rows on average - its tiles then fetch 8.7 GB per dots pass against 6.1 algorithmic - so the chunk's
+  // order is cut into 4, 16, 64 runs of levels, each reordered on its own (xcd_rcm_permutation), until they are: 16 pieces
+  // there (level sets of ~200 rows, 7.5 GB). SLQ_RCM_SUB fixes the number of pieces.
   if (try_tiles && tmode == 2 && reorder_mode != 0) {
+    if (sub_env <= 0) {
+      double w = 0.0;
+      for (int k = 1; k <= 64; k *= 4) {
+        xcd_rcm_permutation(n, rowptr, colind, rcm_perm, k, &w);
+        if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: %d piece(s) per chunk: level sets of %.0f rows on average\n", k, w);
+        if (w <= kTileLevelRows) break;
+      }
+    }
     std::vector<int32_t> order;
     if (cluster_tiles(&rcm_order(), order)) {
       have_tiles = true;
       if (!adopt(order)) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+    } else if (sub_env <= 0) {
+      rcm_perm.clear();  // declined: the generic passes keep their own (one-piece) order, decided below
     }
   }
   bool want = false;
@@ -1336,7 +1366,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->esz = esize(op->dtype);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   tiles_mode() != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
@@ -2025,7 +2055,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR);
       const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
       // the alpha-only pass of a symmetric operator stays on the upper triangle (half the gathers) rather than the ring
-      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr && env_int("SLQ_RING_ALPHA", 0) == 0);
+      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr && !p->sw.ring_alpha);
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   do {                                                                                               \
     if (tl)                                                                                          \

@@ -767,6 +767,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 #ifndef SLQ_RING_LAG
 #define SLQ_RING_LAG 2
 #endif
+#ifndef SLQ_RING_GROUPS
+#define SLQ_RING_GROUPS 2
+#endif
+#ifndef SLQ_RING_CHUNK
+#define SLQ_RING_CHUNK 4
+#endif
 #ifndef SLQ_RING_WAVES
 #define SLQ_RING_WAVES 16
 #endif
@@ -778,10 +784,12 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 #endif
 constexpr int kRingWaves = SLQ_RING_WAVES;  // a consumer's work per row is a chain of LDS latencies: many consumer waves hide it
 constexpr int kRingBlock = kRingWaves * 64;
+constexpr int kRingChunk = SLQ_RING_CHUNK;  // nonzeros of a row gathered per batch (power of two)
 constexpr int kRingLoaders = SLQ_RING_LOADERS;
+constexpr int kRingGroups = SLQ_RING_GROUPS;  // consumer groups taking the tiles in turn: a wave's prefetch runs kRingGroups tiles ahead
 constexpr int kRingSlots = SLQ_RING_SLOTS;
 constexpr int kRingLag = SLQ_RING_LAG;        // a loader's tiles in flight
-constexpr int kRingTileRows = SLQ_RING_ROWS;  // one row per consumer wave
+constexpr int kRingTileRows = SLQ_RING_ROWS;  // two rows per consumer wave of a group
 constexpr int kRingTileCols = SLQ_RING_COLS;  // distinct panel rows per tile at most
 constexpr int kRingTileNnz = 160;             // nonzeros per tile at most: the record fits kRingMetaBytes in fp64
 constexpr int kRingMetaBytes = 2048;          // 4 slots x (36 + 2) KiB + kRingHeadBytes = 156 KiB
@@ -793,6 +801,7 @@ constexpr int kDescCols = 0, kDescRecOff = 1, kDescRecChunks = 2, kDescRow0 = 3,
 // record words: [0 .. rows] row offsets into the record's own nonzeros, [15] byte offset of the values,
 // [16 .. 16 + rows) line of each row's own panel row, then from byte 128 the column lines (int32) and the values (F)
 constexpr int kRecValOff = 15, kRecSelf = 16, kRecHeadBytes = 128;
+static_assert((kRingWaves - kRingLoaders) % kRingGroups == 0 && kRingSlots % kRingGroups == 0, "every slot is served by one consumer group");
 static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders <= 3 && kRingTileRows <= 15 && kRingTileCols <= 64 - kDescList, "ring geometry");
 static_assert(kRingWaves <= 16 && (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes) + kRingHeadBytes <= 160 * 1024, "ring slots must fit the LDS");
 static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes), "the final reduction reuses the slots");
@@ -831,7 +840,8 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
   constexpr int LPR = 64;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
   constexpr int NX = RC > 2 ? RC - 2 : 1;
-  constexpr int NC = kRingWaves - kRingLoaders;      // consumer waves
+  constexpr int NCW = kRingWaves - kRingLoaders;     // consumer waves, in kRingGroups groups that take the tiles in turn
+  constexpr int NC = NCW / kRingGroups;              // consumer waves of one tile
   constexpr int MR = (kRingTileRows + NC - 1) / NC;  // rows of a tile per consumer wave
   constexpr int kSlotBytes = kRingTileCols * 1024 + kRingMetaBytes;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -907,6 +917,11 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
     for (int i = 0; i < kRingLag - 1; ++i) hist[i] = 0;
     bool ok = true;
     for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
+#ifdef SLQ_DEBUG_TIMES
+      // diagnostic build (scripts/ring_timeline.py): workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles
+      unsigned long long *dbg = (PASS == PASS_ADOTS && g_dbg_times && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? g_dbg_times + (size_t)k * 8 : nullptr;
+      if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+#endif
       stage_desc(k + kRingLag - 1);
       // descriptor k is here and tile k - kRingLag has landed once only what was issued after descriptor k is outstanding:
       // the DMAs of tiles k - kRingLag + 1 .. k - 1 and the kRingLag - 1 descriptor requests since
@@ -915,12 +930,18 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
       for (int i = 0; i < kRingLag - 1; ++i) since += hist[i];
       wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
       if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % kRingSlots);
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
+#endif
       int issued = 0;
       if (k < ntiles) {
         const int slot = k % kRingSlots;
         int dcur;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dcur) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + (k & 3) * 256) + lane * 4) : "memory");
         if (k >= kRingSlots) ok = spin(done + slot, NC * (k / kRingSlots));  // the slot's previous tile has been consumed
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (ok) {
           unsigned char *img = slots + (size_t)slot * kSlotBytes;
           const int D = lane_bcast(dcur, kDescCols);
@@ -940,13 +961,19 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
           }
         }
       }
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) {
+        dbg[3] = __builtin_amdgcn_s_memrealtime();
+        dbg[7] = (unsigned long long)issued;
+      }
+#endif
 #pragma unroll
       for (int i = kRingLag - 2; i > 0; --i) hist[i] = hist[i - 1];
       hist[0] = issued;
     }
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------
-    const int cw = wave - kRingLoaders;
+    const int grp = (wave - kRingLoaders) / NC, cw = (wave - kRingLoaders) % NC;  // this wave serves tiles grp, grp + G, ...
     const int colbase = panel * PW + lane * V;
     VF sc, cp, cb = (VF)(F)0;
     VF gm[RC > 0 ? RC : 1];
@@ -977,13 +1004,15 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
         }
       }
     };
-    int dcur = load_desc(0), dnext = load_desc(1);
+    constexpr int G = kRingGroups;
+    int dcur = load_desc(grp), dnext = load_desc(grp + G);
     fetch_rows(lane_bcast(dcur, kDescRow0), lane_bcast(dcur, kDescRows));
     bool ok = true;
-    for (int k = 0; k < ntiles && ok; ++k) {
+    if (grp >= ntiles) ok = false;  // (fewer tiles than groups: nothing to prefetch either; rows stay undefined, unused)
+    for (int k = grp; k < ntiles && ok; k += G) {
       const int slot = k % kRingSlots;
       const int r_lo = lane_bcast(dcur, kDescRow0), nrows = lane_bcast(dcur, kDescRows);
-      const int dnext2 = load_desc(k + 2);
+      const int dnext2 = load_desc(k + 2 * G);
       VF xpc[MR], uc[MR][NX];
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
@@ -991,9 +1020,16 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
 #pragma unroll
         for (int q = 0; q < NX; ++q) uc[i][q] = un[i][q];
       }
-      if (k + 1 < ntiles) fetch_rows(lane_bcast(dnext, kDescRow0), lane_bcast(dnext, kDescRows));
+      if (k + G < ntiles) fetch_rows(lane_bcast(dnext, kDescRow0), lane_bcast(dnext, kDescRows));
+#ifdef SLQ_DEBUG_TIMES
+      unsigned long long *dbg = (PASS == PASS_ADOTS && g_dbg_times && blockIdx.x == 0 && blockIdx.y == 0 && cw == 0 && k < 256) ? g_dbg_times + (size_t)k * 8 : nullptr;
+      if (dbg && lane == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+#endif
       ok = spin(ready + slot, kRingLoaders * (k / kRingSlots + 1));
       if (!ok) break;
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
+#endif
       const unsigned char *img = slots + (size_t)slot * kSlotBytes;
       const F *xl = (const F *)img + lane * V;
       const unsigned char *rec = img + kRingTileCols * 1024;
@@ -1008,18 +1044,18 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
         const VF xp = first ? (VF)(F)0 : xpc[i];
         const VF xc = *(const VF *)(xl + (size_t)si * PW);
         VF acc = (VF)(F)0;
-        for (int pb = p0; pb < p1; pb += 8) {
+        // the row's entries are fetched kRingChunk at a time by the first lanes and broadcast with v_readlane; entries past
+        // the row's end read the row's own image line with a zero coefficient, so a chunk's image reads go out back to back
+        for (int pb = p0; pb < p1; pb += kRingChunk) {
           const int cnt = p1 - pb;
-          // lanes 0-7 fetch the entries, v_readlane broadcasts them; entries past the row's end read the row's own image
-          // line with a zero coefficient, so the eight image reads go out back to back
-          const int e = min(pb + (lane & 7), p1 - 1);
+          const int e = min(pb + (lane & (kRingChunk - 1)), p1 - 1);
           const int lcv = *(const int *)(rec + kRecHeadBytes + e * 4);
           const F vav = *(const F *)(rec + valoff + e * (int)sizeof(F));
-          VF x[8];
+          VF x[kRingChunk];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) x[q] = *(const VF *)(xl + (size_t)(q < cnt ? lane_bcast(lcv, q) : si) * PW);
+          for (int q = 0; q < kRingChunk; ++q) x[q] = *(const VF *)(xl + (size_t)(q < cnt ? lane_bcast(lcv, q) : si) * PW);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc += (q < cnt ? lane_bcast(vav, q) : (F)0) * x[q];
+          for (int q = 0; q < kRingChunk; ++q) acc += (q < cnt ? lane_bcast(vav, q) : (F)0) * x[q];
         }
         VF w = sc * acc;
         if (!first) w -= cp * xp;
@@ -1050,6 +1086,9 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
       // every LDS read of this wave from the slot has returned before the release
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) bump(done + slot);
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+#endif
       dcur = dnext;
       dnext = dnext2;
     }

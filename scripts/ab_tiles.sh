@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for mode in 0 default; do
   if [ "$mode" = "default" ]; then unset SLQ_TILES; else export SLQ_TILES=$mode; fi
   echo "== SLQ_TILES=$mode: f64, 256 probes"
-  bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode} "default" "lap2d_1000:3 lap2d_1000:0 lap2d_1000:6 lap3d_100:3 lap3d_100:0" --no-extra
+  bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode} "default" "lap2d_1000:3 lap2d_1000:0 lap2d_1000:6 lap3d_100:3 lap3d_100:0 lap3d_100:6" --no-extra
   echo "== SLQ_TILES=$mode: f32, 512 probes, k = 50"
   bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode}_f32 "default" "lap2d_1400:3 lap3d_126:3" --no-extra --dtype f32 --probes 512 --deg 50
   echo "== SLQ_TILES=$mode: narrow panel, 64 probes (tiles unused; the row order is the tiles')"
