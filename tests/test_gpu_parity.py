@@ -5,6 +5,8 @@ per-probe quadratic forms 1e-10 relative against the oracle on identical probes 
 bar is 1e-6); fp32 2e-4; integer structure (steps, shapes, nnz, Rademacher support) bit-exact.
 """
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -383,6 +385,7 @@ def test_full_size_properties_c2(eng, oracle):
 	n = L2.shape[0]
 	logdet = 1166809.9080624094  # closed form, BASELINE.md §2
 	plan = eng.LanczosPlan(op, 256, 30, 3)
+	assert plan.describe()["tiles"] == 2  # the default path of this operator: ring-fed LDS tiles
 	plan.generate_probes("rademacher", seed=1234)
 	plan.run()
 	q = plan.quadrature("log")
@@ -425,6 +428,44 @@ def test_full_size_properties_c2(eng, oracle):
 	p0.generate_probes("rademacher", seed=1234)
 	p0.run()
 	np.testing.assert_allclose(p0.quadrature("log"), q_all[:16], rtol=1e-10)
+
+
+def test_full_size_north_star_operator_on_the_default_path(eng, oracle):
+	"""The north_star's operator at full size (3-D 7-point Laplacian 100^3, nnz = 6.94 M, 256 probes, k = 30) as a user runs
+	it - tiles, second-level row order and all: the oracle on the first and last column of each panel at orth 3 and 0, the
+	generic passes (SLQ_TILES=0 is a different stored order and different kernels) to rounding, run-to-run bitwise."""
+	A = laplacian_3d(100)
+	op = eng.DeviceOperator(A)
+	cols = [0, 127, 128, 255]
+	res = {}
+	for orth in (3, 0):
+		plan = eng.LanczosPlan(op, 256, 30, orth)
+		assert plan.describe()["tiles"] == 2
+		plan.generate_probes("rademacher", seed=77)
+		V = plan.get_probes()[:, cols]
+		plan.run()
+		q = plan.quadrature("log")
+		ref = oracle.quad_batch(A, np.asfortranarray(V), 30, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(q[cols], ref, rtol=1e-10)
+		plan.generate_probes("rademacher", seed=77)
+		plan.run()
+		assert np.array_equal(plan.quadrature("log"), q)
+		res[orth] = q
+		plan.close()
+	np.testing.assert_allclose(res[0], res[3], rtol=1e-8)  # reorthogonalisation moves a 30-step rule of this operator far below 1e-6
+	op.close()
+	os.environ["SLQ_TILES"] = "0"
+	try:
+		op0 = eng.DeviceOperator(A)
+		plan = eng.LanczosPlan(op0, 256, 30, 3)
+		assert plan.describe()["tiles"] == 0
+		plan.generate_probes("rademacher", seed=77)
+		plan.run()
+		np.testing.assert_allclose(plan.quadrature("log"), res[3], rtol=1e-11)
+		plan.close()
+		op0.close()
+	finally:
+		del os.environ["SLQ_TILES"]
 
 
 def test_3d_laplacian_north_star_variant(oracle, eng):
