@@ -125,6 +125,7 @@ struct Switches {
   int cross;       // SLQ_CROSS     q_c.q_p from the update pass's cross term
   int tiles;       // SLQ_TILES     fused passes on the operator's LDS workgroup tiles (when it has them)
   int ring_alpha;  // SLQ_RING_ALPHA the alpha-only pass through the ring too, even where the upper triangle is available
+  int ring_rev;    // SLQ_RING_REV  the ring-fed update pass sweeps panels and tiles in reverse (it starts where the dots pass ended)
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
@@ -133,7 +134,7 @@ struct Switches {
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -1432,7 +1433,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->esz = esize(op->dtype);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 0) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 0) != 0, env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
@@ -2062,7 +2063,8 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
         // the ring-fed variant: flag words and descriptor staging + kRingSlots slots; 16 waves per workgroup
         const size_t lds_ring = kRingHeadBytes + (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes);
         k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, op->tile_desc, op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
-                                                                               p->st.coefB, p->st.gamma, p->part, p->bpad, xt, p->ring_fail_d);
+                                                                               p->st.coefB, p->st.gamma, p->part, p->bpad,
+                                                                               xt | ((PASS == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0), p->ring_fail_d);
         return;
       }
     }

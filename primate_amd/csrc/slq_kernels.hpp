@@ -853,7 +853,10 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
   double *red = (double *)slots;  // the final reduction (kRingWaves*64*V doubles) runs when the slots are dead
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int panel = blockIdx.y;
+  // xt bit 2: sweep the panels and the tiles of every chunk in REVERSE order. The update pass does, so that each pass begins
+  // where the one before it ended: the rows touched last are the ones still in the Infinity Cache / L2.
+  const int rev = (xt >> 2) & 1;
+  const int panel = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + lane * V;
   xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
@@ -895,7 +898,11 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
   };
   auto bump = [&](lds_int *w) { asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)w), "v"(1) : "memory"); };
   // descriptor of the k-th tile of this workgroup, one word per lane (tiles past the end: the last one again, unused)
-  auto load_desc = [&](int k) -> int { return tile_desc[(int64_t)(t_first + min(k, ntiles - 1) * nbl) * 64 + lane]; };
+  auto tile_at = [&](int k) -> int64_t {  // this workgroup's k-th tile (past the end: its last one again)
+    const int kk = min(k, ntiles - 1);
+    return (int64_t)(t_first + (rev ? ntiles - 1 - kk : kk) * nbl);
+  };
+  auto load_desc = [&](int k) -> int { return tile_desc[tile_at(k) * 64 + lane]; };
   if (ntiles > 0 && wave < kRingLoaders) {
     // ---------------- loader ----------------
     // Descriptors reach the loader through LDS as well (a 256-byte DMA into a small staging ring, read back with an
@@ -903,7 +910,7 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
     // compiler drain vmcnt to 0 at every use, and with it the DMAs meant to stay in flight.
     unsigned char *stage = lds_raw + 256 + (size_t)wave * 4 * 256;  // 4 descriptors per loader, after the flag words
     auto stage_desc = [&](int k) {
-      const int32_t *src = tile_desc + (int64_t)(t_first + min(k, ntiles - 1) * nbl) * 64 + lane;
+      const int32_t *src = tile_desc + tile_at(k) * 64 + lane;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(stage + (k & 3) * 256), 4, 0, 0);
     };
