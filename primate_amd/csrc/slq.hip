@@ -90,6 +90,7 @@ struct slq_operator {
   std::vector<int32_t> *perm_h;  // host copy (diag un-permutation)
   TileMeta tiles;                // workgroup LDS tiles of the fused passes (tile_ptr == null: none; SLQ_TILES)
   bool tiles_ringed = false;     // ... built to the caps of k_csr_ring_pass (SLQ_TILES=2), which reads these two:
+  int32_t *inv_perm_d = nullptr; // device: caller row r is stored row inv_perm[r] (null if not reordered)
   int32_t *tile_desc = nullptr;  // 64 words per tile
   char *tile_rec = nullptr;      // the tiles' CSR records
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
@@ -849,6 +850,9 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     vals = va2.data();
     hipError_t pe = hipMalloc((void **)&op->perm_d, (size_t)n * 4);
     if (pe == hipSuccess) pe = hipMemcpyAsync(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (pe == hipSuccess) pe = hipMalloc((void **)&op->inv_perm_d, (size_t)n * 4);
+    if (pe == hipSuccess) pe = hipMemcpyAsync(op->inv_perm_d, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);  // (inv is a local)
     if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
   }
   {
@@ -1205,6 +1209,7 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->vals_a) hipFree(op->vals_a);
   if (op->vals_b) hipFree(op->vals_b);
   if (op->perm_d) hipFree(op->perm_d);
+  if (op->inv_perm_d) hipFree(op->inv_perm_d);
   delete op->perm_h;
   if (op->rowptr_u) hipFree(op->rowptr_u);
   if (op->colind_u) hipFree(op->colind_u);
@@ -1835,19 +1840,11 @@ extern "C" int slq_plan_generate_probes(slq_plan *p, int pdf, uint64_t seed, uin
   const int items = (p->n + (pdf == 0 ? 127 : 1)) / (pdf == 0 ? 128 : 2);
   const int gx = std::max(1, std::min(p->ctx->num_cus * 8, (items + 4 * RPW - 1) / (4 * RPW)));
   dim3 g(gx, p->NP);
-  if (p->op->perm_d) {
-    // stored row order differs from the caller's: element-wise generator, same (seed, id, row) stream
-    dim3 gp(std::max(1, std::min(p->ctx->num_cus * 8, (p->n + 4 * RPW - 1) / (4 * RPW))), p->NP);
-    PROFILED(p, SLQ_K_PROBES,
-             DISPATCH(p->dtype, p->LPR,
-                      (k_gen_probes_perm<F, L><<<gp, dim3(256), 0, st>>>(p->n, (F *)slot_ptr(p, 0), pdf == SLQ_PDF_RADEMACHER ? 0 : 1,
-                                                                         seed, probe_offset, p->nprobes, p->op->perm_d))));
-  } else {
+  // (an operator stored as P A P^T: the rows are scattered through the inverse permutation - the same (seed, id, row) stream)
   PROFILED(p, SLQ_K_PROBES,
            DISPATCH(p->dtype, p->LPR,
                     (k_gen_probes<F, L><<<g, dim3(256), 0, st>>>(p->n,
-                                        (F *)slot_ptr(p, 0), pdf, seed, probe_offset, p->nprobes))));
-  }
+                                        (F *)slot_ptr(p, 0), pdf, seed, probe_offset, p->nprobes, p->op->inv_perm_d))));
   p->pdf_sphere = (pdf == SLQ_PDF_SPHERE);
   return init_from_probes(p, p->pdf_sphere);
 }

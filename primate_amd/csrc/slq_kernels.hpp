@@ -2035,28 +2035,6 @@ __device__ __forceinline__ F probe_element(int pdf, uint32_t k0, uint32_t k1, ui
   return (F)(rad * ((row & 1) ? sn : cs));
 }
 
-// Generator for an operator stored as P A P^T: panel row i holds caller row perm[i].
-template <typename F, int LPR>
-__global__ __launch_bounds__(256) void k_gen_probes_perm(int n, F *W, int pdf, uint64_t seed, uint64_t probe_offset,
-                                                         int nprobes, const int32_t *__restrict__ perm) {
-  using VF = typename VecT<F>::type;
-  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / LPR, cl = lane % LPR;
-  const int panel = blockIdx.y;
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  const int col0 = panel * PW + cl * V;
-  F *dst = W + ((int64_t)panel * n) * PW + cl * V;
-  for (int i = (blockIdx.x * 4 + wave) * RPW + g; i < n; i += gridDim.x * 4 * RPW) {
-    const int row = perm[i];
-    VF x;
-#pragma unroll
-    for (int v = 0; v < V; ++v)
-      x[v] = (col0 + v < nprobes) ? probe_element<F>(pdf, k0, k1, probe_offset + (uint64_t)(col0 + v), row) : (F)0;
-    *(VF *)(dst + (int64_t)i * PW) = x;
-  }
-}
-
 // Column-major generator (stand-alone entry slq_dmat_generate): X[row, c] = element (seed, probe id0 + c, row)
 // of the same stream as the panel generators. One thread per row, columns walked in the loop.
 __global__ __launch_bounds__(256) void k_gen_cols(int64_t n, double *X, int nc, int pdf01, uint64_t seed, uint64_t id0) {
@@ -2084,7 +2062,8 @@ __global__ __launch_bounds__(256) void k_scale_cols_sphere(int64_t n, double *X)
 
 template <typename F, int LPR>
 __global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64_t seed,
-                                                    uint64_t probe_offset, int nprobes) {
+                                                    uint64_t probe_offset, int nprobes,
+                                                    const int32_t *__restrict__ inv /* caller row -> panel row; null: identity */) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2116,7 +2095,7 @@ __global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64
           VF x;
 #pragma unroll
           for (int v = 0; v < V; ++v) x[v] = ((r[v][b >> 5] >> (b & 31)) & 1u) ? (F)1 : (F)-1;
-          *(VF *)(dst + (int64_t)row * PW) = x * mask;
+          *(VF *)(dst + (int64_t)(inv ? inv[row] : row) * PW) = x * mask;
         }
       }
     } else {
@@ -2134,8 +2113,8 @@ __global__ __launch_bounds__(256) void k_gen_probes(int n, F *W, int pdf, uint64
         xb[v] = (F)(rad * sn);
       }
       const int row = it * 2;
-      if (row < n) *(VF *)(dst + (int64_t)row * PW) = xa * mask;
-      if (row + 1 < n) *(VF *)(dst + (int64_t)(row + 1) * PW) = xb * mask;
+      if (row < n) *(VF *)(dst + (int64_t)(inv ? inv[row] : row) * PW) = xa * mask;
+      if (row + 1 < n) *(VF *)(dst + (int64_t)(inv ? inv[row + 1] : row + 1) * PW) = xb * mask;
     }
   }
 }
