@@ -93,6 +93,8 @@ struct slq_operator {
   int32_t *inv_perm_d = nullptr; // device: caller row r is stored row inv_perm[r] (null if not reordered)
   int32_t *tile_desc = nullptr;  // 64 words per tile
   char *tile_rec = nullptr;      // the tiles' CSR records
+  int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
+  char *tile_rec_u = nullptr;
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
@@ -125,7 +127,8 @@ struct Switches {
   int merged;      // SLQ_MERGED    alpha from the merged alpha+dots pass
   int cross;       // SLQ_CROSS     q_c.q_p from the update pass's cross term
   int tiles;       // SLQ_TILES     fused passes on the operator's LDS workgroup tiles (when it has them)
-  int ring_alpha;  // SLQ_RING_ALPHA the alpha-only pass through the ring too, even where the upper triangle is available
+  int ring_alpha;  // SLQ_RING_ALPHA the alpha-only pass of a tiled symmetric operator: 2 ring over the upper-triangle stream, 1 ring over
+                   //               the full rows, 0 the generic upper-triangle pass
   int ring_rev;    // SLQ_RING_REV  the ring-fed update pass sweeps panels and tiles in reverse (it starts where the dots pass ended)
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
@@ -188,6 +191,7 @@ struct slq_plan {
 // is created (whether its passes use them).
 constexpr int kTilesDefault = 2;
 constexpr double kTileMaxColsPerRow = 4.5;      // tiles are kept when a tile row needs at most this many distinct panel rows
+constexpr double kTileAlphaColsPerRow = 2.0;    // upper-triangle tiles: the alpha-only pass takes the ring up to this many landed rows per row
 constexpr double kTileLevelRows = 320.0;        // level sets the tile sweep's base order should not exceed (csr_create_impl)
 
 static int env_int(const char *name, int dflt) {
@@ -885,10 +889,11 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   // scalar q^T A q, so it can run on the upper triangle with doubled off-diagonals and gather half the
   // panel rows. Built only when the stored CSR is EXACTLY symmetric (pattern and values, sorted rows
   // without duplicates); anything else keeps the full rows. SLQ_SYM_ALPHA=0 disables it.
+  std::vector<int32_t> urp, uci;  // the upper triangle (stored order), kept for the tile stream of the alpha-only pass below
+  std::vector<char> uva;
+  bool sym = false;
   if (!plain && env_int("SLQ_SYM_ALPHA", 1) != 0 && nnz > 0) {
-    std::vector<int32_t> urp, uci;
-    std::vector<char> uva;
-    bool sym = dtype == SLQ_F64 ? build_symmetric_upper<double>(n, rowptr, colind, (const double *)vals, urp, uci, uva)
+    sym = dtype == SLQ_F64 ? build_symmetric_upper<double>(n, rowptr, colind, (const double *)vals, urp, uci, uva)
                                 : build_symmetric_upper<float>(n, rowptr, colind, (const float *)vals, urp, uci, uva);
     if (sym) {
       const size_t nu = uci.size();
@@ -942,6 +947,25 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec, rec.size());
       if (te == hipSuccess) te = hipMemcpy(op->tile_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
       if (te == hipSuccess) te = hipMemcpy(op->tile_rec, rec.data(), rec.size(), hipMemcpyHostToDevice);
+      if (te == hipSuccess && sym) {
+        // the same tiles over the upper triangle (doubled off-diagonals), for the alpha-only pass: a tile's image then holds its
+        // own rows and the neighbours of HIGHER index only - about half the halo, and the pass is bound by what it lands by DMA
+        std::vector<int32_t> tpu, tcu, lcu, siu;
+        int mxu = 0;
+        build_tile_meta(n, urp.data(), uci.data(), tile_row, tpu, tcu, lcu, siu, &mxu);
+        // ... which is ~24-28 GB/s per CU: worth it while the tiles land at most kTileAlphaColsPerRow panel rows
+        // per row (5-point grid: 1.5 - 0.53 against 0.57 ms for the generic pass; 7-point grid: 2.5 - 0.87 against 0.82 ms)
+        const double upper_per_row = (double)(tcu.size() - kCsrPad) / (double)n;
+        if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row\n", upper_per_row);
+        if (upper_per_row <= kTileAlphaColsPerRow) {
+          if (dtype == SLQ_F64) build_ring_stream<double>(urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
+          else build_ring_stream<float>(urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
+          te = hipMalloc((void **)&op->tile_desc_u, desc.size() * 4);
+          if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec.size());
+          if (te == hipSuccess) te = hipMemcpy(op->tile_desc_u, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
+          if (te == hipSuccess) te = hipMemcpy(op->tile_rec_u, rec.data(), rec.size(), hipMemcpyHostToDevice);
+        }
+      }
     }
     if (te != hipSuccess) {
       slq_operator_destroy(op);
@@ -1221,6 +1245,8 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->tiles.self_idx) hipFree((void *)op->tiles.self_idx);
   if (op->tile_desc) hipFree(op->tile_desc);
   if (op->tile_rec) hipFree(op->tile_rec);
+  if (op->tile_desc_u) hipFree(op->tile_desc_u);
+  if (op->tile_rec_u) hipFree(op->tile_rec_u);
   ctx_release(op->ctx);
   delete op;
   return SLQ_OK;
@@ -1438,7 +1464,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->esz = esize(op->dtype);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 0) != 0, env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 2), env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
@@ -2059,7 +2085,8 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
       if (op->tiles_ringed) {
         // the ring-fed variant: flag words and descriptor staging + kRingSlots slots; 16 waves per workgroup
         const size_t lds_ring = kRingHeadBytes + (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes);
-        k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, op->tile_desc, op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
+        const bool upper = PASS == PASS_ALPHA && op->tile_desc_u != nullptr && p->sw.ring_alpha == 2;
+        k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, upper ? op->tile_desc_u : op->tile_desc, upper ? op->tile_rec_u : op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
                                                                                p->st.coefB, p->st.gamma, p->part, p->bpad,
                                                                                xt | ((PASS == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0), p->ring_fail_d);
         return;
@@ -2120,7 +2147,10 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR);
       const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
       // the alpha-only pass of a symmetric operator stays on the upper triangle (half the gathers) rather than the ring
-      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr && !p->sw.ring_alpha);
+      // the alpha-only pass of a symmetric operator: ring-fed over the upper-triangle stream where the operator has one
+      // (SLQ_RING_ALPHA=2, default; else the generic upper-triangle pass), ring-fed over the full rows (1), generic (0)
+      const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr &&
+                                          (p->sw.ring_alpha == 0 || (p->sw.ring_alpha == 2 && op->tile_desc_u == nullptr)));
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   do {                                                                                               \
     if (tl)                                                                                          \
