@@ -1733,6 +1733,7 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
     std::vector<const void *> ring_fns = {
         (const void *)k_csr_ring_pass<F, PASS_ALPHA, 0, 0>, (const void *)k_csr_ring_pass<F, PASS_ALPHA, 1, 0>,
         (const void *)k_csr_ring_pass<F, PASS_UPDATE, 0, 0>, (const void *)k_csr_ring_pass<F, PASS_UPDATE, 1, 0>,
+        (const void *)k_csr_ring_pass<F, PASS_SPMM, 0, 0>, (const void *)k_csr_ring_pass<F, PASS_SPMM, 1, 0>,
 #define RING_RC(R)                                                                                              \
   (const void *)k_csr_ring_pass<F, PASS_ADOTS, 0, R>, (const void *)k_csr_ring_pass<F, PASS_ADOTS, 1, R>,       \
       (const void *)k_csr_ring_pass<F, PASS_UPDATE, 0, R>, (const void *)k_csr_ring_pass<F, PASS_UPDATE, 1, R>
@@ -2077,7 +2078,7 @@ static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStrea
 // the same pass on workgroup tiles (wide panels only; slq_kernels.hpp: k_csr_tile_pass)
 template <typename F, int L, int PASS, int LP, int RC>
 static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStream_t st, int j, int xt) {
-  if constexpr (L == 64 && (PASS == PASS_ALPHA || PASS == PASS_ADOTS || PASS == PASS_UPDATE)) {
+  if constexpr (L == 64 && (PASS == PASS_ALPHA || PASS == PASS_ADOTS || PASS == PASS_UPDATE || PASS == PASS_SPMM)) {
     const slq_operator *op = p->op;
     TileRanges xr;
     for (int x = 0; x < 9; ++x) xr.first[x] = op->tiles.xcd_tile[x];
@@ -2092,6 +2093,7 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
         return;
       }
     }
+    if constexpr (PASS != PASS_SPMM)
     k_csr_tile_pass<F, PASS, LP, RC><<<grid, dim3(kBlock), lds, st>>>(p->n, op->rowptr, (const F *)op->vals, op->tiles.tile_row, op->tiles.tile_ptr,
                                                                     op->tiles.tile_cols, op->tiles.lcol, op->tiles.self_idx, xr, op->tiles.max_cols, (F *)p->ring,
                                                                     p->slot_stride, p->S, j, p->st.coefA, p->st.coefB, p->st.gamma, p->part, p->bpad, xt);
@@ -2218,7 +2220,15 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       prev_xt = (xt_u & 1) != 0;
     } else {
     prev_xt = false;
-    if (op->kind == OP_CSR) {
+    if (op->kind == OP_CSR && plan_tiled(p) && op->tiles_ringed) {
+      // the sweeps' SpMM + three-term step on the ring-fed tiles (k_csr_ring_pass<PASS_SPMM>): same result slot, same alpha partials
+      PROFILED(p, SLQ_K_SPMM, {
+        if (nt) DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS_SPMM, 1, 0>(p, gT, 0, st, j, 0)));
+        else DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS_SPMM, 0, 0>(p, gT, 0, st, j, 0)));
+      });
+      PROFILED(p, SLQ_K_FINALIZE,
+               hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkT, j, 0));
+    } else if (op->kind == OP_CSR) {
       const int pol = nt ? 11 : 0;  // tens digit: load policy, units: store policy
       const size_t spmm_pad = (size_t)p->sw.spmm_pad;  // dynamic LDS only to cap residency at 2 per CU (panel after panel: 38.8 -> 34.7 ms per 26 launches at orth 30)
 #define SPMM_LAUNCH(LP, SP)                                                                          \

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // i = 1..RC-1 and k_fin_adots forms alpha and the projections exactly as lanczos.h:59-63,127-135 would, up to
 // rounding. Column i = 0 (W_c itself) needs no sums: q_c.(u - alpha q_c) = alpha (1 - |q_c|^2) is pure
 // rounding of alpha - in the reference too, where it stays below the 2 eps sqrt(n) threshold - so gamma_0 = 0.
-enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3 };
+enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3, PASS_SPMM = 4 /* ring kernel only: k_spmm_3term's job */ };
 
 template <typename F, int LPR, int PASS, int NTP, int RC, int PIPE>
 __global__ __launch_bounds__(kBlock) void k_csr_pass(
@@ -1067,6 +1067,9 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
         VF w = sc * acc;
         if (!first) w -= cp * xp;
         if (PASS == PASS_ALPHA) {
+          acc1 += (sc * xc) * w;
+        } else if (PASS == PASS_SPMM) {  // the store-and-revisit sequence's first sweep: w = A q_c - beta q_p stored, alpha partials
+          stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += (sc * xc) * w;
         } else if (PASS == PASS_ADOTS) {
           acc1 += (sc * xc) * w;

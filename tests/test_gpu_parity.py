@@ -674,9 +674,15 @@ def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch, var
 			plan = eng.LanczosPlan(op, P, 12, 3)
 			assert plan.describe()["tiles"] == 2
 			plan.close()
-			for o in (0, 3, 5):  # 5: steps with more than 3 ring columns take the generic passes on the tiles' row order
+			## 5: steps with more than 3 ring columns take the generic passes on the tiles' row order; 12: above 8 the store-and-revisit
+			## sweeps, whose SpMM + three-term sweep is the ring kernel's PASS_SPMM on this operator
+			for o in (0, 3, 5, 12):
 				ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, o, fun="log", fresh_q=True)
 				np.testing.assert_allclose(eng.quad_batch(op, X, 12, o, fun="log")[cols], ref, rtol=tol, err_msg=f"ring n={n} {A.dtype} orth={o}")
+			monkeypatch.setenv("SLQ_MGS", "1")  # exact MGS order: sweeps from the first step on
+			ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, 3, fun="log", fresh_q=True)
+			np.testing.assert_allclose(eng.quad_batch(op, X, 12, 3, fun="log")[cols], ref, rtol=tol, err_msg=f"ring n={n} {A.dtype} MGS order")
+			monkeypatch.delenv("SLQ_MGS")
 			op.close()
 	cases = [(laplacian_2d(70), "24", "0"), (laplacian_3d(17), "16", "2"), (laplacian_2d(66), "7", "0")]
 	for A, tr, reorder in cases:
