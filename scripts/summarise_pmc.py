@@ -33,7 +33,7 @@ def classify(name: str, orth: int):
 		return {"0": "spmm_3term", "1": "reorth_dot", "3": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm"}[m.group(3)]
 	m = re.search(r"k_csr_(?:ring|tile)_pass<(\w+), (\d), ", name)  # the tiled forms of the same passes: <F, PASS, ...>
 	if m:
-		return {"0": "spmm_3term", "1": "reorth_dot", "3": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm"}[m.group(2)]
+		return {"0": "spmm_3term", "4": "spmm_3term", "1": "reorth_dot", "3": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm"}[m.group(2)]
 	for k, c in (("k_spmm_3term", "spmm_3term"), ("k_reorth_dot", "reorth_dot"), ("k_reorth_update", "reorth_update")):
 		if k in name:
 			return c
