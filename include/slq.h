@@ -108,8 +108,9 @@ int slq_context_device(slq_context *ctx, int *device);
  * src/primate/include/eigen_operators.h:64). */
 int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr,
                    const int32_t *colind, const void *vals, slq_operator **out);
-/* Same, arrays already on the device: copied device-to-device into the operator's own (padded) storage,
- * so the caller may free them after the call. Not validated: column indices must lie in [0, n). */
+/* Same, arrays already on the device. The operator is built exactly as by slq_csr_create (validated, reordered, upper
+ * triangle, tiles): those decisions are taken on the host, so one copy of the arrays is read back (once), and the caller
+ * may free its arrays after the call. */
 int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                           const int32_t *d_rowptr, const int32_t *d_colind, const void *d_vals,
                           slq_operator **out);

@@ -987,35 +987,25 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   if (!d_rowptr || (nnz > 0 && (!d_colind || !d_vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
   HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
-  slq_operator *op = new (std::nothrow) slq_operator();
-  if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
-  ctx_retain(ctx);
-  // The kernels read colind/vals up to kCsrPad entries past nnz (gather_row_uniform), which a caller's arrays do not
-  // guarantee: the operator owns padded device-to-device copies (rowptr is copied too, so that the caller may free
-  // all three). The arrays are NOT validated (they live on the device): indices must lie in [0, n).
-  *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
+  // The operator is built the way slq_csr_create builds it - validated, reordered, with its upper triangle and its tiles -
+  // and all of that is decided on the host: one copy of the CSR arrays comes back (12-16 bytes per nonzero, once), the operator's
+  // own storage is uploaded from it, and the caller's arrays are not referenced after the call.
   const size_t es = esize(dtype);
-  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
-  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
-  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, d_rowptr, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream);
-  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, d_colind, (size_t)nnz * 4, hipMemcpyDeviceToDevice, ctx->stream);
-  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, d_vals, (size_t)nnz * es, hipMemcpyDeviceToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    slq_operator_destroy(op);
-    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "device CSR copy: %s", hipGetErrorString(e));
+  std::vector<int32_t> rp, ci;
+  std::vector<char> va;
+  try {
+    rp.resize((size_t)n + 1);
+    ci.resize((size_t)nnz);
+    va.resize((size_t)nnz * es);
+  } catch (const std::bad_alloc &) {
+    return fail(SLQ_ENOMEM, "host allocation failed");
   }
-  *out = op;
-  return SLQ_OK;
+  HIP_TRY(hipMemcpy(rp.data(), d_rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+  if (nnz) HIP_TRY(hipMemcpy(ci.data(), d_colind, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+  if (nnz) HIP_TRY(hipMemcpy(va.data(), d_vals, (size_t)nnz * es, hipMemcpyDeviceToHost));
+  return csr_create_impl(ctx, dtype, n, nnz, rp.data(), ci.data(), va.data(), out, 0);
 }
 
-// Gram operator x -> A^T (A x) of a rectangular CSR matrix A (mrows x ncols): the symmetric positive semidefinite
-// operator Lanczos sees is ncols x ncols (eigen_operators.h:57-72, SparseEigenLinearOperator<F, true>; what numrank /
-// singular-value functions of a rectangular matrix use). A and its transpose (built here) live on the device; a
-// product is two plain panel SpMMs.
 extern "C" int slq_csr_gram_create(slq_context *ctx, int dtype, int64_t mrows, int64_t ncols, int64_t nnz, const int32_t *rowptr,
                                    const int32_t *colind, const void *vals, slq_operator **out) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");

@@ -95,7 +95,8 @@ class DeviceOperator:
 
 	Accepted inputs mirror the six overloads of the reference FFI
 	(src/primate/_lanczos.cpp:102-112): ndarray (dense), scipy.sparse (any format; stored as CSR
-	with int32 indices), or any object with `.matvec` and `.shape` (host-callback fallback).
+	with int32 indices), or any object with `.matvec` and `.shape` (host-callback fallback); beyond them a
+	torch sparse-CSR tensor that already lives on the context's GPU (slq_csr_create_device).
 	"""
 
 	def __init__(self, A, dtype=None, ctx: Optional[Context] = None):
@@ -103,6 +104,10 @@ class DeviceOperator:
 
 		self.ctx = ctx or default_context()
 		L = _capi.lib()
+		## a torch sparse-CSR tensor on the GPU: slq_csr_create_device (its arrays are read from HBM, never through numpy)
+		torch_csr = type(A).__module__.split(".")[0] == "torch" and str(getattr(A, "layout", "")) == "torch.sparse_csr"
+		if torch_csr and dtype is None:
+			dtype = {"torch.float64": np.float64, "torch.float32": np.float32}[str(A.dtype)]
 		if dtype is None:
 			dtype = getattr(A, "dtype", np.float64)
 		self.dtype = np.dtype(dtype)
@@ -112,7 +117,22 @@ class DeviceOperator:
 		self.shape = (int(A.shape[0]), int(A.shape[1]))
 		self._keep = []
 		h = C.c_void_p()
-		if isinstance(A, np.ndarray):
+		if torch_csr:
+			import torch
+
+			if not A.is_cuda:
+				raise ValueError("a torch sparse-CSR operator must live on the GPU (use scipy.sparse for host matrices)")
+			if A.device.index != self.ctx.device:
+				raise ValueError(f"the matrix is on {A.device}, the context on GPU {self.ctx.device}")
+			tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+			crow = A.crow_indices().to(torch.int32).contiguous()
+			col = A.col_indices().to(torch.int32).contiguous()  # (sorted within each row, as torch builds them)
+			val = A.values().to(tdt).contiguous()
+			torch.cuda.synchronize(A.device)
+			check(L.slq_csr_create_device(self.ctx._h, dt, self.shape[0], int(val.numel()), C.c_void_p(crow.data_ptr()), C.c_void_p(col.data_ptr()),
+										 C.c_void_p(val.data_ptr()), C.byref(h)))  # fmt: skip
+			self.kind, self.nnz = "csr", int(val.numel())
+		elif isinstance(A, np.ndarray):
 			M = np.asfortranarray(A, dtype=self.dtype)
 			check(L.slq_dense_create(self.ctx._h, dt, M.shape[0], ptr(M), M.shape[0], C.byref(h)))
 			self.kind, self.nnz = "dense", M.size

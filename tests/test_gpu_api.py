@@ -518,3 +518,26 @@ def test_torch_plugin_operator_stays_on_the_device():
 
 	with pytest.raises(RuntimeError, match="plugin failure"):
 		quad_batch(DeviceOperator(TorchOperator(boom, 300)), X, 5, 0)
+
+
+def test_device_resident_csr_operator_is_built_like_a_host_one():
+	"""slq_csr_create_device (a torch sparse-CSR tensor on the GPU): the operator goes through the same analysis as a scipy
+	matrix - reordering, upper triangle, LDS tiles - so its results are the host-created operator's bit for bit, and bad
+	indices are refused."""
+	from primate_amd import engine as eng
+
+	torch = pytest.importorskip("torch")
+	A = laplacian_2d(300)  # 90,000 rows: takes the tiles by default
+	T = torch.sparse_csr_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)), torch.from_numpy(A.data), size=A.shape).cuda()
+	op_d, op_h = eng.DeviceOperator(T), eng.DeviceOperator(A)
+	assert op_d.kind == "csr" and op_d.nnz == A.nnz and op_d.dtype == np.float64
+	pd, ph = eng.LanczosPlan(op_d, 130, 10, 3), eng.LanczosPlan(op_h, 130, 10, 3)
+	assert pd.describe() == ph.describe() and pd.describe()["tiles"] == 2
+	for p in (pd, ph):
+		p.generate_probes("rademacher", seed=5)
+		p.run()
+	assert np.array_equal(pd.quadrature("log"), ph.quadrature("log"))
+	pd.close(), ph.close(), op_d.close(), op_h.close()
+	bad = torch.sparse_csr_tensor(torch.tensor([0, 1, 2]), torch.tensor([0, 5]), torch.tensor([1.0, 1.0]), size=(2, 2), check_invariants=False).cuda()
+	with pytest.raises(ValueError):
+		eng.DeviceOperator(bad)
