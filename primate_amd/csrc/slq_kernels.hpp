@@ -736,23 +736,26 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
   }
 }
 
-// ---- the tiled passes with a continuously fed ring of tile images (opt-in, SLQ_TILES=2) -----------------------------
+// ---- the tiled passes with a continuously fed ring of tile images (SLQ_TILES=2, the default for stencil-like operators;
+// DESIGN.md §4.1a) ---------------------------------------------------------------------------------------------------
 // k_csr_tile_pass alternates "land a tile, barrier, compute it, barrier": a CU's memory pipe is idle half the time, and
 // every wave walks the CSR with dependent scalar loads. Here the workgroup (one per CU, kRingWaves = 16 waves) splits into
-// kRingLoaders LOADER waves and the rest CONSUMER waves around a ring of kRingSlots slots in LDS, and EVERYTHING a tile needs arrives
-// in its slot by LDS-DMA: the image (its distinct panel rows, 1 KiB each) and a RECORD of its CSR (row offsets, the
-// position of every row's own line, per nonzero the line of its column and the value - see RingRecord below).
+// kRingLoaders LOADER waves and the rest CONSUMER waves around a ring of kRingSlots slots in LDS, and EVERYTHING a tile
+// needs arrives in its slot by LDS-DMA: the image (its distinct panel rows, 1 KiB each) and a RECORD of its CSR (row
+// offsets, the line of every row's own panel row, per nonzero the line of its column and the value; layout below).
 //  * every tile has a 256-byte DESCRIPTOR (tile_desc, 64 ints: counts, where its record and rows start, its distinct
-//    panel rows) that one wave reads with ONE coalesced load, two tiles ahead, so no scalar-memory round trip sits
+//    panel rows) that a wave gets with ONE coalesced request, tiles ahead of its use, so no scalar-memory round trip sits
 //    between tiles (scalar loads share lgkmcnt with LDS and return out of order: one in flight turns every LDS wait into
 //    a wait for memory);
 //  * a loader, per tile k: requests descriptor k + kRingLag - 1; waits with ONE counted s_waitcnt vmcnt(N) (N = its DMAs
-//    of the kRingLag - 1 tiles before k plus the descriptor requests since descriptor k's) - which says both "descriptor k is here" and "tile k - kRingLag has
-//    landed"; publishes that tile (ready[slot] += 1); waits until the consumers have released slot k % kRingSlots
-//    (done[slot]); issues its share of tile k's DMAs. kRingLag tiles of DMAs per loader stay in flight throughout;
-//  * a consumer wave prefetches the row-local streams (W_p, ring columns) of its rows of tile k + 1 into registers, polls
-//    ready[slot(k)] in LDS, computes its rows of tile k out of the slot (CSR entries fetched by lanes 0-7 and broadcast
-//    with v_readlane), and releases the slot (done[slot] += 1).
+//    of the kRingLag - 1 tiles before k plus the descriptor requests since descriptor k's) - which says both "descriptor
+//    k is here" and "tile k - kRingLag has landed"; publishes that tile (ready[slot] += 1); waits until the consumers
+//    have released slot k % kRingSlots (done[slot]); issues its share of tile k's DMAs. kRingLag tiles of DMAs per loader
+//    stay in flight throughout;
+//  * the consumer waves form kRingGroups groups that take the tiles in turn. A wave prefetches the row-local streams
+//    (W_p, ring columns) of its rows of its NEXT tile - kRingGroups tiles ahead - into registers, polls ready[slot(k)]
+//    in LDS, computes its rows of tile k out of the slot (CSR entries fetched kRingChunk at a time by the first lanes and
+//    broadcast with v_readlane), and releases the slot (done[slot] += 1).
 // Nothing but these LDS counters synchronises the waves inside the loop; every poll is bounded (kRingSpinMax, then the
 // workgroup raises *fail and leaves: the host reports the run as failed instead of hanging the GPU).
 #ifndef SLQ_RING_LOADERS
