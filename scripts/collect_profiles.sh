@@ -3,7 +3,7 @@
 # HBM-traffic PMC passes (each counter in its own pass, with --kernel-trace only, per the pool's rules).
 # usage: bash scripts/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...
 set -eo pipefail
-TAG=${1:-r02a}
+TAG=${1:-r02b}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
