@@ -12,6 +12,10 @@ collective (weak scaling: 256 probes per GPU; probe ids are global, so results d
     python bench.py [--gpus N] [--steps K] [--warmup W] [--orth R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no WORLD_SIZE in the environment (a bare `python bench.py --gpus N`) the process starts its own N
+ranks (spawn_ranks: child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything here touches
+torch or HIP), relays rank 0's line and exits with the worst child's code.
+
 Prints ONE JSON line on rank 0.
 """
 
@@ -280,6 +284,56 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	return {"line": line, "A": A, "n": n, "deg": deg, "orth": orth}
 
 
+def spawn_ranks(n, argv, cmd=None, timeout=None):
+	"""Start `n` ranks of this script as CHILD processes (one per GPU: LOCAL_RANK = RANK), relay rank 0's stdout, return the
+	worst exit code. The parent never imports torch and never initialises a GPU, and nothing is re-executed in place: a
+	process that holds a HIP context must not exec (the box refuses it), so the launcher stays a plain parent. `cmd`
+	replaces `[python, bench.py]` (the CPU test of this function runs a stub)."""
+	import socket
+	import subprocess
+
+	with socket.socket() as sk:  # a free rendezvous port, unless the caller fixed one
+		sk.bind(("127.0.0.1", 0))
+		port = sk.getsockname()[1]
+	base = dict(os.environ)
+	base.setdefault("MASTER_ADDR", "127.0.0.1")
+	base.setdefault("MASTER_PORT", str(port))
+	base["WORLD_SIZE"] = str(n)
+	base["LOCAL_WORLD_SIZE"] = str(n)
+	cmd = list(cmd) if cmd is not None else [sys.executable, str(Path(__file__).resolve())]
+	procs = []
+	for r in range(n):
+		env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+		## rank 0 owns the JSON line; whatever other ranks print goes to stderr so that stdout stays ONE line
+		procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+	t_end = None if timeout is None else time.monotonic() + timeout
+	out0 = b""
+	try:
+		out0, _ = procs[0].communicate(timeout=timeout)
+		for p in procs[1:]:
+			p.wait(timeout=None if t_end is None else max(1.0, t_end - time.monotonic()))
+	except subprocess.TimeoutExpired:
+		pass
+	finally:
+		for p in procs:  # exactly the children started above, nothing by pattern
+			if p.poll() is None:
+				p.terminate()
+		for p in procs:
+			try:
+				p.wait(timeout=20)
+			except subprocess.TimeoutExpired:
+				p.kill()
+				p.wait()
+	sys.stdout.write(out0.decode(errors="replace"))
+	sys.stdout.flush()
+	codes = [p.returncode for p in procs]
+	bad = [c for c in codes if c != 0]
+	if bad:
+		print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+		return max(abs(c) for c in bad) or 1
+	return 0
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -296,11 +350,13 @@ def main():
 	ap.add_argument("--cpu-seconds", type=float, default=15.0)
 	args = ap.parse_args()
 
+	N = args.gpus
+	if N > 1 and "WORLD_SIZE" not in os.environ:
+		sys.exit(spawn_ranks(N, sys.argv[1:]))  # a bare `python bench.py --gpus N`: be the launcher (torch is not imported yet)
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
-	N = args.gpus
-	assert world == N or (N == 1 and world == 1), f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run"
+	assert world == N or (N == 1 and world == 1), f"--gpus {N} but WORLD_SIZE={world}"
 
 	import torch
 

@@ -279,6 +279,16 @@ typedef struct {
 int slq_plan_profile_enable(slq_plan *plan, int enable);
 int slq_plan_profile_read(slq_plan *plan, slq_profile *out, int reset);
 
+/* Failure reporting of the ring-fed tile pass (k_csr_ring_pass). Every wait inside that kernel is bounded; a workgroup
+ * whose wait runs out raises a device word and leaves, and every accessor that hands results of a run to the host
+ * (slq_plan_get_tridiag, _quadrature, _get_basis, _fun_action[_dmat], slq_diag_update, the one-shot entries) then returns
+ * SLQ_EHIP instead of undefined numbers (the reference's kernel has no failure mode of its own:
+ * src/primate/include/lanczos.h:92-149 is noexcept host code). Two hooks for the tests:
+ *   slq_debug_ring_flag_status   the flag -> status translation those accessors share (no device work: CPU-testable)
+ *   slq_debug_plan_poke_ring_flag  sets a plan's device word as an aborting workgroup would */
+int slq_debug_ring_flag_status(int flag);
+int slq_debug_plan_poke_ring_flag(slq_plan *plan, int value);
+
 /* ---- one-shot entries ---------------------------------------------------------------------------- */
 /* P probes in one call: the batched counterpart of the Python loop at
  * src/primate/operators.py:145-150. X: host column-major n x nprobes, or NULL to draw probes on

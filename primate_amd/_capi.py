@@ -101,6 +101,8 @@ _SIGNATURES = {
 	"slq_fAv_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, C.c_int64]),
 	"slq_lanczos_f64": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P, _P, C.c_size_t]),
 	"slq_lanczos_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P, _P, C.c_size_t]),
+	"slq_debug_ring_flag_status": (C.c_int, [C.c_int]),
+	"slq_debug_plan_poke_ring_flag": (C.c_int, [_P, C.c_int]),
 }  # fmt: skip
 DEVICE_MATMAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 class PlanInfo(C.Structure):

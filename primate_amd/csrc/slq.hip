@@ -1071,13 +1071,21 @@ extern "C" int slq_csr_affine_create(slq_context *ctx, int dtype, int64_t n, int
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
   *out = nullptr;
   SLQ_TRY(check_dtype(dtype));
-  if (n <= 0 || !rp_a || !rp_b || rp_a[0] != 0 || rp_b[0] != 0 || rp_a[n] != nnz_a || rp_b[n] != nnz_b)
-    return fail(SLQ_EINVAL, "bad CSR arrays for the affine operator");
+  if (n <= 0 || n >= (int64_t)1 << 31 || nnz_a < 0 || nnz_b < 0 || nnz_a >= (int64_t)1 << 31 || nnz_b >= (int64_t)1 << 31)
+    return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices");
+  if (!rp_a || !rp_b || (nnz_a > 0 && (!ci_a || !va)) || (nnz_b > 0 && (!ci_b || !vb))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  if (rp_a[0] != 0 || rp_b[0] != 0 || rp_a[n] != nnz_a || rp_b[n] != nnz_b)
+    return fail(SLQ_EINVAL, "rowptr[0] must be 0 and rowptr[n] must equal nnz");
+  for (int64_t i = 0; i < n; ++i)
+    if (rp_a[i + 1] < rp_a[i] || rp_b[i + 1] < rp_b[i]) return fail(SLQ_EINVAL, "rowptr is not non-decreasing at %lld", (long long)i);
   const size_t es = esize(dtype);
-  std::vector<int32_t> rp((size_t)n + 1, 0), ci;
+  std::vector<int32_t> rp, ci;
   std::vector<char> ua, ub;
   std::vector<std::pair<int32_t, int>> a_row, b_row;
   const char zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  try {
+  rp.assign((size_t)n + 1, 0);
+  ci.reserve((size_t)std::max(nnz_a, nnz_b));
   for (int64_t i = 0; i < n; ++i) {
     a_row.clear();
     b_row.clear();
@@ -1096,7 +1104,11 @@ extern "C" int slq_csr_affine_create(slq_context *ctx, int dtype, int64_t n, int
       if (ca == c) { memcpy(ua.data() + ua.size() - es, (const char *)va + (size_t)a_row[x].second * es, es); ++x; }
       if (cb == c) { memcpy(ub.data() + ub.size() - es, (const char *)vb + (size_t)b_row[y].second * es, es); ++y; }
     }
+    if (ci.size() >= ((size_t)1 << 31)) return fail(SLQ_EINVAL, "the union pattern exceeds int32 indices");
     rp[(size_t)i + 1] = (int32_t)ci.size();
+  }
+  } catch (const std::bad_alloc &) {  // no C++ exception crosses the C boundary
+    return fail(SLQ_ENOMEM, "host allocation failed");
   }
   const int64_t nnz = (int64_t)ci.size();
   // the union pattern with A's values is an ordinary CSR operator; keep its rows as given (no reordering, no upper-triangle
@@ -1160,7 +1172,13 @@ extern "C" int slq_dense_create(slq_context *ctx, int dtype, int64_t n, const vo
     e = hipMemcpy2DAsync(op->vals, (size_t)n * es, A, (size_t)lda * es, (size_t)n * es, (size_t)n,
                          hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && !symmetric) {
-    std::vector<char> T((size_t)n * n * es);
+    std::vector<char> T;
+    try {
+      T.resize((size_t)n * n * es);
+    } catch (const std::bad_alloc &) {
+      slq_operator_destroy(op);
+      return fail(SLQ_ENOMEM, "host allocation failed");
+    }
     for (int64_t j = 0; j < n; ++j)
       for (int64_t i = 0; i < n; ++i)
         memcpy(T.data() + ((size_t)j * n + i) * es, (const char *)A + ((size_t)i * lda + j) * es, es);  // T(i,j) = A(j,i)
@@ -1405,6 +1423,22 @@ extern "C" int slq_plan_query_bytes(int dtype, int64_t n, int nprobes, int deg, 
   choose_geometry(dtype, nprobes, &LPR, &PW, &NP);
   const size_t S = ring_slots(deg, orth, keep_basis);
   *bytes = S * (size_t)NP * (size_t)n * PW * esize(dtype);
+  return SLQ_OK;
+}
+
+// What a plan on `op` allocates: the ring (slq_plan_query_bytes) plus the product panels of operators that are not applied
+// row by row inside the passes - T (dense / callback / Gram: one panel; the fp64 dense MFMA kernel with big tiles adds up to
+// 16 split-K slabs) and T2 (Gram: the m-row intermediate). The one-shot entries size their probe chunks from this.
+static int plan_bytes_on(const slq_operator *op, int nprobes, int deg, int orth, int keep_basis, size_t *bytes) {
+  SLQ_TRY(slq_plan_query_bytes(op->dtype, op->n, nprobes, deg, orth, keep_basis, bytes));
+  int LPR, PW, NP;
+  choose_geometry(op->dtype, nprobes, &LPR, &PW, &NP);
+  const size_t panel = (size_t)NP * PW * esize(op->dtype);
+  if (op->kind != OP_CSR) {
+    const bool big_tiles = op->kind == OP_DENSE && op->dtype == SLQ_F64 && PW >= 32;
+    *bytes += (size_t)(1 + (big_tiles ? 16 : 0)) * panel * (size_t)op->n;
+  }
+  if (op->kind == OP_GRAM) *bytes += panel * (size_t)op->mrows;
   return SLQ_OK;
 }
 
@@ -1748,6 +1782,30 @@ static int set_kernel_attributes(slq_plan *p) {
 
 // the plan's fused passes run on the operator's workgroup tiles: wide panels (one row per wave) of an operator that has them
 static bool plan_tiled(const slq_plan *p) { return p->LPR == 64 && p->op->tiles.tile_ptr != nullptr && p->sw.tiles; }
+
+// k_csr_ring_pass raises *ring_fail_d when one of its bounded waits ran out (slq_kernels.hpp: kRingSpinMax): everything the
+// plan holds is then undefined. ring_flag_status() is the flag -> status translation (no HIP call in it: a CPU test covers
+// it through slq_debug_ring_flag_status); check_ring_flag() reads the device word behind whatever the caller has enqueued
+// and is called by EVERY accessor that hands results of a run to the host.
+static int ring_flag_status(int flag) {
+  if (flag) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
+  return SLQ_OK;
+}
+static int check_ring_flag(slq_plan *p) {
+  int flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, p->ring_fail_d, sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  return ring_flag_status(flag);
+}
+extern "C" int slq_debug_ring_flag_status(int flag) { return ring_flag_status(flag); }
+// test hook: set the plan's device flag as an aborting workgroup would (tests/test_gpu_api.py)
+extern "C" int slq_debug_plan_poke_ring_flag(slq_plan *p, int value) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  HIP_TRY(hipMemcpyAsync(p->ring_fail_d, &value, sizeof(int), hipMemcpyHostToDevice, p->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  return SLQ_OK;
+}
 
 // which launch sequence the steps with r <= kFusedMaxR take (enqueue_run): 0 sweeps, 1 recompute passes, 2 stored u
 static int plan_sequence(const slq_plan *p) {
@@ -2354,7 +2412,7 @@ extern "C" int slq_plan_get_tridiag(slq_plan *p, void *alpha, void *beta, int32_
   int ring_bad = 0;
   HIP_TRY(hipMemcpyAsync(&ring_bad, p->ring_fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (ring_bad) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
+  SLQ_TRY(ring_flag_status(ring_bad));
   for (int i = 0; i < P; ++i) {
     for (int t = 0; t <= deg; ++t) {
       const double a = ha[(size_t)t * bp + i];
@@ -2397,7 +2455,7 @@ extern "C" int slq_plan_quadrature(slq_plan *p, int fun_id, const double *fun_pa
   if (weights) HIP_TRY(hipMemcpyAsync(weights, p->weights_d, (size_t)P * deg * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   const int bad = bad2[0];
-  if (bad2[1]) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
+  SLQ_TRY(ring_flag_status(bad2[1]));
   if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
   return SLQ_OK;
 }
@@ -2412,7 +2470,7 @@ extern "C" int slq_plan_get_basis(slq_plan *p, int probe, void *Q, int64_t ldq) 
   const int bp = p->bpad, deg = p->deg;
   std::vector<double> hn((size_t)(deg + 1) * bp), hscale((size_t)deg * bp, 0.0);
   HIP_TRY(hipMemcpyAsync(hn.data(), p->st.nu, hn.size() * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  SLQ_TRY(check_ring_flag(p));
   for (int t = 0; t < deg; ++t) {
     const double nu = hn[(size_t)t * bp + probe];
     hscale[(size_t)t * bp + probe] = nu > 0.0 ? 1.0 / nu : 0.0;
@@ -2485,7 +2543,7 @@ static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) 
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  SLQ_TRY(check_ring_flag(p));  // (synchronises)
   if (bad) return fail(SLQ_ENOTCONV, "tridiagonal QL did not converge for at least one probe");
   return SLQ_OK;
 }
@@ -2966,7 +3024,7 @@ extern "C" int slq_quad_batch(slq_context *ctx, slq_operator *op, const void *X,
   int chunk = nprobes;
   for (;;) {
     size_t need = 0;
-    SLQ_TRY(slq_plan_query_bytes(op->dtype, op->n, chunk, d, o, 0, &need));
+    SLQ_TRY(plan_bytes_on(op, chunk, d, o, 0, &need));
     if (need + ((size_t)1 << 30) <= free_b || chunk <= 8) break;
     chunk = (chunk + 1) / 2;
   }
@@ -3003,7 +3061,7 @@ extern "C" int slq_fAv_batch(slq_context *ctx, slq_operator *op, const void *X, 
   int chunk = nvec;
   for (;;) {
     size_t need = 0;
-    SLQ_TRY(slq_plan_query_bytes(op->dtype, op->n, chunk, d, o, 1, &need));
+    SLQ_TRY(plan_bytes_on(op, chunk, d, o, 1, &need));
     if (need + ((size_t)1 << 30) <= free_b || chunk <= 8) break;
     chunk = (chunk + 1) / 2;
   }

@@ -441,6 +441,18 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
             else if (diag & (1u << k)) acc += a8[k] * xc;
           }
         }
+        if (p0 == p1) {
+          // a row without stored entries never enters the batch loop: the prefetch state still advances ONE row per row
+          // (otherwise every later row of this wave would reuse the empty row's pointers and come out as -cp * W_p)
+          pn0 = pq0;
+          pn1 = pq1;
+          cn = *(const csr_i8 *)(colind + pq0);
+          const int rn2 = r0 + 2 * stride;
+          if (!reuse && rn2 < r_end) {
+            pq0 = rowptr[rn2];
+            pq1 = rowptr[rn2 + 1];
+          }
+        }
         p = p1;
       }
       for (; p + 4 <= p1; p += 4) {
@@ -805,7 +817,7 @@ constexpr int kDescCols = 0, kDescRecOff = 1, kDescRecChunks = 2, kDescRow0 = 3,
 // [16 .. 16 + rows) line of each row's own panel row, then from byte 128 the column lines (int32) and the values (F)
 constexpr int kRecValOff = 15, kRecSelf = 16, kRecHeadBytes = 128;
 static_assert((kRingWaves - kRingLoaders) % kRingGroups == 0 && kRingSlots % kRingGroups == 0, "every slot is served by one consumer group");
-static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders <= 3 && kRingTileRows <= 15 && kRingTileCols <= 64 - kDescList, "ring geometry");
+static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders <= 3 && kRingTileRows < kRecValOff && kRecSelf + kRingTileRows <= 32 && kRingTileCols <= 64 - kDescList, "ring geometry");
 static_assert(kRingWaves <= 16 && (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes) + kRingHeadBytes <= 160 * 1024, "ring slots must fit the LDS");
 static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes), "the final reduction reuses the slots");
 static_assert(kRecHeadBytes + ((kRingTileNnz + 3) / 4 * 4) * (4 + 8) <= kRingMetaBytes, "a tile's record must fit its slot");

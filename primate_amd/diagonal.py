@@ -89,27 +89,3 @@ def diag(
 		result.estimate, result.nit = estimator.estimate, len(estimator)
 		return (estimator.estimate, result)
 	return estimator.estimate
-
-
-def xdiag(A, m: Optional[int] = None, pdf: str = "sphere", seed: Union[int, np.random.Generator, None] = None) -> np.ndarray:
-	"""XDiag (Epperly et al.) with m/2 products with A and m/2 with A^T; src/primate/diagonal.py:99-138.
-	Dense n x (m/2) host algebra around two operator products."""
-	m = 2 * A.shape[0] if m is None else min(m + (m % 2), 2 * A.shape[0])
-	n, m = A.shape[0], m // 2
-	col_dot = lambda X, Y: np.einsum("ij,ij->j", X, Y)[:, None]  # noqa: E731  diag(X^T Y) as a column
-	rng = np.random.default_rng(seed=seed)
-	draw = isotropic(pdf=pdf, seed=rng)
-	Om = draw(size=(n, m))
-	Y = A @ Om
-	Q, R = np.linalg.qr(Y, mode="reduced")
-	d_omy = np.einsum("ij,ij->i", Om, Y)[:, None]
-	Z = A.T @ Q
-	T = Z.T @ Om
-	R_inv = np.linalg.inv(R)
-	S = R_inv.T / np.linalg.norm(R_inv, axis=1)
-	QS = Q @ S
-	d_qz = np.einsum("ij,ij->i", Q, Z)[:, None]
-	d_qssz = np.einsum("ij,ij->i", QS, Z @ S)[:, None]
-	d_omtq = np.einsum("ij,ij->i", Om, Q @ T)[:, None]
-	d_omqsst = np.einsum("ij,ij->i", Om, (col_dot(S, T) * QS.T).T)[:, None]
-	return (d_qz + (-d_qssz + d_omy - d_omtq + d_omqsst) / m).ravel()

@@ -220,29 +220,35 @@ def _hutchpp_device(A, nb: int, mode: str, draw: Callable, chunk: int = 128) -> 
 	return rng_ests, defl_ests
 
 
-def _xtrace_small(n: int, Wq: np.ndarray, H: np.ndarray, T: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:
-	"""Leave-one-out XTrace estimates from the m x m summaries Wq = Q^T W, H = Q^T Z, T = Z^T W
-	(Epperly, Tropp & Webber; the algebra of src/primate/trace.py:199-227). Returns an (m, 1) column."""
-	cdot = lambda X, Y: np.einsum("ij,ij->j", X, Y)[:, None]  # noqa: E731  column-wise dot products
-	m = Wq.shape[0]
-	S = R_inv.T / np.linalg.norm(R_inv, axis=1)
-	if pdf != "sphere":
-		scale = np.ones((m, 1))
+def _leave_one_out_estimates(n: int, QtW: np.ndarray, QtZ: np.ndarray, ZtW: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:
+	"""XTrace's m exchangeable estimates from m x m summaries only (QtW = Q^T W, QtZ = Q^T A Q, ZtW = (A Q)^T W, A W = Q R).
+
+	Estimate i is "trace of A on span(Q) with probe i's direction s_i taken out" plus "Hutchinson's estimate of probe i on
+	what is left" (Epperly, Tropp & Webber, XTrace; what src/primate/trace.py:199-227 evaluates). s_i is the i-th row of
+	R^{-1} scaled to unit length: removing column i of W from the sketch downdates Q by exactly that direction, so every
+	term below is a column-wise product of m x m matrices - nothing of size n is touched. Returns an (m, 1) column."""
+	m = QtW.shape[0]
+	colsum = lambda X, Y: np.einsum("ij,ij->j", X, Y)  # noqa: E731  (x_i . y_i) for every column i
+	S = R_inv.T / np.linalg.norm(R_inv, axis=1)  # downdate directions, unit columns
+	s_w = colsum(S, QtW)  # s_i . (Q^T w_i)
+	s_h_s = colsum(S, QtZ @ S)  # s_i^T (Q^T A Q) s_i
+	G = QtZ @ QtW
+	## part 1: tr(Q_(i)^T A Q_(i)) with Q_(i) = Q minus the direction s_i
+	on_span = np.trace(QtZ) - s_h_s
+	## part 2: w_i^T (I - Q_(i) Q_(i)^T) A (I - Q_(i) Q_(i)^T) w_i, expanded in the summaries (the A w_i = Q r_i terms cancel
+	## against R; what survives pairs s_i with the residuals R - G and ZtW - QtZ^T QtW)
+	off_span = colsum(QtW, G) - colsum(ZtW, QtW) + s_w * (colsum(S, R - G) + colsum(ZtW - QtZ.T @ QtW, S) + s_w * s_h_s)
+	if pdf == "sphere":
+		## probes on the sphere of radius sqrt(n): the projected probe is rescaled to the complement's dimension n - m + 1
+		weight = (n - m + 1) / (n - np.linalg.norm(QtW, axis=0) ** 2 + (s_w * np.linalg.norm(S, axis=0)) ** 2)
 	else:
-		c = n - m + 1
-		scale = c / (n - np.linalg.norm(Wq, axis=0)[:, None] ** 2 + (cdot(S, Wq) * np.linalg.norm(S, axis=0)[:, None]) ** 2)
-	HW = H @ Wq
-	dSW, dSHS = cdot(S, Wq), cdot(S, H @ S)
-	dTW, dWHW = cdot(T, Wq), cdot(Wq, HW)
-	dSRmHW, dTmHRS = cdot(S, R - HW), cdot(T - H.T @ Wq, S)
-	ests = np.trace(H) * np.ones((m, 1)) - dSHS
-	ests += (-dTW + dWHW + dSW * dSRmHW + np.abs(dSW) ** 2 * dSHS + dTmHRS * dSW) * scale
-	return ests
+		weight = 1.0
+	return (on_span + weight * off_span)[:, None]
 
 
 def _xtrace(W: np.ndarray, Z: np.ndarray, Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, pdf) -> np.ndarray:
 	"""XTrace estimates for the m probes in W; Z = A Q, Q R = A W, R_inv = R^{-1} (trace.py:185-227)."""
-	return _xtrace_small(W.shape[0], Q.T @ W, Q.T @ Z, Z.T @ W, R, R_inv, pdf)
+	return _leave_one_out_estimates(W.shape[0], Q.T @ W, Q.T @ Z, Z.T @ W, R, R_inv, pdf)
 
 
 def _qr_append_block(Q: np.ndarray, R: np.ndarray, R_inv: np.ndarray, Y: np.ndarray) -> tuple:
@@ -362,7 +368,7 @@ def _xtrace_device(A, batch: int, draw: Callable, budget: int, record: bool, cal
 			R, R_inv = R_new, Ri_new
 			apply_fun(Qd, m, ns, Zd, m)
 			m += ns
-			t_samples = _xtrace_small(n, Qd.tn(0, m, Wd, 0, m), Qd.tn(0, m, Zd, 0, m), Zd.tn(0, m, Wd, 0, m), R, R_inv, None)
+			t_samples = _leave_one_out_estimates(n, Qd.tn(0, m, Wd, 0, m), Qd.tn(0, m, Zd, 0, m), Zd.tn(0, m, Wd, 0, m), R, R_inv, None)
 			estimator = MeanEstimator(record=record)
 			estimator.update(t_samples.ravel())
 			result.estimator, result.estimate, result.nit = estimator, estimator.estimate, m

@@ -26,7 +26,7 @@ for nm in ("tn", "add_product", "set", "get"):
 	setattr(engine.DeviceMatrix, nm, timed("dmat." + nm, getattr(engine.DeviceMatrix, nm)))
 for nm in ("run", "fun_action_into", "set_probes_device"):
 	setattr(engine.LanczosPlan, nm, timed("plan." + nm, getattr(engine.LanczosPlan, nm)))
-trace._xtrace_small = timed("xtrace_small(host)", trace._xtrace_small)
+trace._leave_one_out_estimates = timed("leave_one_out_estimates(host)", trace._leave_one_out_estimates)
 
 n, k, P = 500000, 40, 512
 rng = np.random.default_rng(1234)

@@ -541,3 +541,53 @@ def test_device_resident_csr_operator_is_built_like_a_host_one():
 	bad = torch.sparse_csr_tensor(torch.tensor([0, 1, 2]), torch.tensor([0, 5]), torch.tensor([1.0, 1.0]), size=(2, 2), check_invariants=False).cuda()
 	with pytest.raises(ValueError):
 		eng.DeviceOperator(bad)
+
+
+def test_ring_bail_out_flag_reaches_every_accessor():
+	"""A workgroup of the ring-fed tile pass whose bounded wait runs out raises the plan's device word; every accessor that
+	hands results to the host must then report SLQ_EHIP, not numbers. The word is poked directly (no kernel is stalled on
+	the box to get there); a plan whose word is clear returns results as usual, and a poked plan stays dead."""
+	from primate_amd import _capi
+	from primate_amd.engine import DeviceMatrix, DeviceOperator, DiagAccumulator, LanczosPlan
+
+	A = laplacian_2d(40)
+	n = A.shape[0]
+	rng = np.random.default_rng(5)
+	X = np.asfortranarray(np.floor(rng.random((n, 6)) * 2) * 2 - 1)
+	op = DeviceOperator(A)
+	plan = LanczosPlan(op, 6, 10, 3, keep_basis=True)
+	plan.set_probes(X)
+	plan.run()
+	good = plan.quadrature("log")
+	assert np.all(np.isfinite(good)) and plan.tridiag()[2].tolist() == [10] * 6
+	_capi.check(_capi.lib().slq_debug_plan_poke_ring_flag(plan._h, 1))
+	out, acc = DeviceMatrix(n, 6), DiagAccumulator(n)
+	calls = {
+		"tridiag": plan.tridiag, "quadrature": lambda: plan.quadrature("log"), "basis": lambda: plan.basis(0),
+		"fun_action": lambda: plan.fun_action("exp"), "fun_action_into": lambda: plan.fun_action_into(out, 0, "exp"),
+		"diag_update": lambda: acc.update(plan, "exp"),
+	}  # fmt: skip
+	for name, call in calls.items():
+		with pytest.raises(_capi.SlqError) as ei:
+			call()
+		assert ei.value.code == _capi.SLQ_EHIP and "ring-fed tile pass" in str(ei.value), name
+	## a second run on the same plan does not clear it: the plan is dead
+	plan.set_probes(X)
+	plan.run()
+	with pytest.raises(_capi.SlqError):
+		plan.quadrature("log")
+	out.close(), acc.close(), plan.close()
+	## a fresh plan on the same operator is unaffected
+	np.testing.assert_array_equal(quad_fresh(op, X), good)
+	op.close()
+
+
+def quad_fresh(op, X):
+	from primate_amd.engine import LanczosPlan
+
+	plan = LanczosPlan(op, X.shape[1], 10, 3, keep_basis=True)
+	plan.set_probes(X)
+	plan.run()
+	q = plan.quadrature("log")
+	plan.close()
+	return q

@@ -627,6 +627,41 @@ def test_non_local_operator_uses_stored_u_passes(oracle, eng, monkeypatch):
 				monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-10), (np.float32, 3e-4)])
+def test_pipelined_row_loop_with_empty_rows(oracle, eng, monkeypatch, dtype, rtol):
+	"""The pipelined row loop of the dots/update passes (k_csr_pass<PIPE=1>: wide panels of operators with more than 5.5
+	nonzeros per row) on a matrix with rows that store NOTHING - isolated nodes of an adjacency-like operator, masked rows.
+	The prefetch state (row pointers two rows ahead, the next row's first indices) advances once per row whatever the
+	row's length; an empty row must not stall it for the rows that follow in the same wave. eigen_operators.h:66-77 (the
+	reference's sparse product has no special case for such rows either)."""
+	rng = np.random.default_rng(12)
+	n = 9000
+	W = sp.random(n, n, density=9.0 / n, random_state=7, format="coo")
+	W = (W + W.T).tolil()
+	dead = np.concatenate([rng.choice(n, 40, replace=False), [0, 1, 2, n - 1, 4096, 4097]])  # scattered, adjacent, first and last rows
+	W[dead, :] = 0
+	W[:, dead] = 0
+	A = (sp.diags(np.where(np.isin(np.arange(n), dead), 0.0, 20.0)) + W.tocsr()).tocsr().astype(dtype)
+	A.eliminate_zeros()
+	A.sort_indices()
+	assert np.all(np.diff(A.indptr)[dead] == 0) and A.nnz / n > 5.5
+	P = 130 if dtype == np.float64 else 260
+	X = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1).astype(dtype)
+	cols = [0, 64, P - 1]
+	monkeypatch.setenv("SLQ_PIPE", "1")
+	monkeypatch.setenv("SLQ_TILES", "0")
+	monkeypatch.setenv("SLQ_FUSED", "2")  # the recompute passes whatever the gather distances
+	op = eng.DeviceOperator(A)
+	plan = eng.LanczosPlan(op, P, 12, 3)
+	assert plan.describe()["pipelined"] == 1 and plan.describe()["sequence"] == "fused"
+	plan.close()
+	for orth in (0, 3, 6):
+		ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, orth, fun="exp", t=-0.01, fresh_q=True, prefer="csr")
+		got = eng.quad_batch(op, X, 12, orth, fun="exp", t=-0.01)[cols]
+		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"orth={orth}")
+	op.close()
+
+
 def test_opt_in_fp32_archive_ring(oracle, eng, monkeypatch):
 	"""SLQ_RING32=1 (opt-in): finished Lanczos vectors archived as fp32, reorthogonalisation columns j-2 and older read
 	from the archive. Not bit-compatible by construction; the bar here is 1e-7 relative per probe against the oracle

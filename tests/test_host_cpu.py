@@ -30,6 +30,24 @@ def test_library_exports_every_declared_symbol():
 	assert L.slq_version() == 100
 
 
+def test_ring_pass_bail_out_is_reported_not_swallowed():
+	"""The ring-fed tile pass bounds every wait; a workgroup that gives up raises a device word, and the accessors turn
+	it into SLQ_EHIP through ONE translation (slq.hip: ring_flag_status). That translation needs no device: a clear flag
+	is SLQ_OK, a raised one SLQ_EHIP with a message that names the pass. (The device side of the report - each accessor
+	reading the word - is tests/test_gpu_api.py::test_ring_bail_out_flag_reaches_every_accessor.)"""
+	from primate_amd import _capi
+
+	L = _capi.lib()
+	assert L.slq_debug_ring_flag_status(0) == _capi.SLQ_OK
+	for raised in (1, 7, -1):
+		assert L.slq_debug_ring_flag_status(raised) == _capi.SLQ_EHIP
+		msg = L.slq_last_error().decode()
+		assert "ring-fed tile pass" in msg and "invalid" in msg
+	with pytest.raises(_capi.SlqError) as ei:
+		_capi.check(L.slq_debug_ring_flag_status(1))
+	assert ei.value.code == _capi.SLQ_EHIP
+
+
 def test_no_gpu_fails_loudly_not_silently():
 	import torch
 
@@ -274,3 +292,24 @@ def test_parallel_rademacher_fill_is_the_same_stream(monkeypatch):
 		tails.append(rng.random(4))
 	assert np.array_equal(outs[0], outs[1]) and np.array_equal(tails[0], tails[1])
 	assert set(np.unique(outs[1])) == {-1.0, 1.0}
+
+
+def test_bench_starts_its_own_ranks(capfd):
+	"""`python bench.py --gpus N` without a launcher: the parent starts N child ranks with RANK / LOCAL_RANK / WORLD_SIZE /
+	MASTER_* set, relays rank 0's stdout only, and returns the worst exit code (one process per GPU). The
+	children here are stubs - no torch, no GPU."""
+	import bench
+
+	stub = "import os, sys; r = int(os.environ['RANK']); print('line', r, os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], bool(int(os.environ['MASTER_PORT']))); sys.exit(int(sys.argv[1]) if r == int(sys.argv[2]) else 0)"
+	rc = bench.spawn_ranks(3, ["0", "0"], cmd=[sys.executable, "-c", stub])
+	out, err = capfd.readouterr()
+	assert rc == 0 and out == "line 0 0 3 127.0.0.1 True\n"  # rank 0's line and nothing else on stdout
+	assert "line 1 1 3" in err and "line 2 2 3" in err
+	rc = bench.spawn_ranks(2, ["5", "1"], cmd=[sys.executable, "-c", stub])  # rank 1 fails with 5
+	out, err = capfd.readouterr()
+	assert rc == 5 and out.startswith("line 0 0 2") and "exit codes [0, 5]" in err
+	## a rank that hangs is ended by the parent (its own child, by handle), the others' result is kept
+	hang = "import os, sys, time; r = int(os.environ['RANK']); print('up', r, flush=True); time.sleep(600 if r == 1 else 0)"
+	rc = bench.spawn_ranks(2, [], cmd=[sys.executable, "-c", hang], timeout=3)
+	out, err = capfd.readouterr()
+	assert rc != 0 and out == "up 0\n"
