@@ -12,11 +12,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <vector>
 
 #include "slq_kernels.hpp"
+#include "slq_ring_api.h"
 
 using namespace slq;
 
@@ -95,6 +97,15 @@ struct slq_operator {
   char *tile_rec = nullptr;      // the tiles' CSR records
   int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
   char *tile_rec_u = nullptr;
+  // narrow panels (slq_ring.hpp): R = 2, 4 consecutive tiles merged into one, built the first time a plan asks for them
+  // (ensure_ring_stream); [0] R = 2, [1] R = 4; *_u over the upper triangle where the operator has that stream
+  struct MergedStream {
+    int32_t *desc = nullptr, *desc_u = nullptr;
+    char *rec = nullptr, *rec_u = nullptr;
+    int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool tried = false;
+  } merged[2];
+  std::mutex *merged_lock = nullptr;
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
@@ -184,6 +195,14 @@ struct slq_plan {
   int S32;
   bool ring32_on;
   int dense_ks;               // dense MFMA operator with big tiles: K split over this many workgroups per row tile (0: 16-row kernel)
+  // ring-fed tile passes (k_csr_ring_pass / k_ring_pass): ringR = panel rows per wave instruction of the tile stream the plan
+  // uses (0: no tiles; 1: the tiles as clustered, 1-KiB panel rows; 2, 4: merged tiles, 512-B / 256-B panel rows)
+  int ringR;
+  bool ring_gen;              // every ring-fed pass of the plan runs k_ring_pass (always for ringR > 1; SLQ_RING_GEN for ringR = 1)
+  bool ring_deep;             // steps with 4..8 ring columns run k_ring_pass with 8 waves (SLQ_RING_DEEP; else the generic passes)
+  const int32_t *rs_desc, *rs_desc_u;  // the stream the plan's ring-fed passes read (full rows / upper triangle or null)
+  const char *rs_rec, *rs_rec_u;
+  int32_t rs_xcd[9];
 };
 
 // SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
@@ -573,37 +592,42 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
   *max_cols = mx;
 }
 
-// What k_csr_ring_pass reads (SLQ_TILES=2; layouts in slq_kernels.hpp): per tile a 64-word descriptor and a record of its
-// CSR in the tile's own numbering, every record at a 16-byte boundary of one blob that ends in a spare record's worth of
-// zeros (a record is fetched in whole KiB).
+// What the ring-fed passes read (SLQ_TILES=2; layouts in slq_kernels.hpp / slq_ring.hpp): per tile a descriptor of R blocks
+// of 64 words and a record of its CSR in the tile's own numbering, every record at a 16-byte boundary of one blob that ends
+// in a spare record's worth of zeros (a record is fetched in whole KiB). R = 1: the tiles as clustered (k_csr_ring_pass and
+// k_ring_pass<LPR = 64>); R = 2, 4: tiles of R merged base tiles for panels of 64 / R lanes per row - block b of the
+// descriptor lists the lines b, R + b, 2R + b, ... (the lines lane group b lands), the last one repeated to the end of its DMA.
 template <typename F>
-static void build_ring_stream(const int32_t *rowptr, const F *vals, const std::vector<int32_t> &tile_row, const std::vector<int32_t> &tile_ptr,
+static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const std::vector<int32_t> &tile_row, const std::vector<int32_t> &tile_ptr,
                               const std::vector<int32_t> &tile_cols, const std::vector<int32_t> &lcol, const std::vector<int32_t> &self_idx,
                               std::vector<int32_t> &desc, std::vector<char> &rec) {
   const size_t ntiles = tile_row.size() - 1;
-  desc.assign(ntiles * 64, 0);
+  const size_t dw = (size_t)64 * R, head_bytes = (size_t)kRecHeadBytes * R;
+  const int valoff_w = 16 * R - 1, self_w = 16 * R;
+  desc.assign(ntiles * dw, 0);
   rec.clear();
   for (size_t t = 0; t < ntiles; ++t) {
     const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
     const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
-    const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = kRecHeadBytes + nzp * 4, bytes = (valoff + nzp * sizeof(F) + 15) / 16 * 16;
+    const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = head_bytes + nzp * 4, bytes = (valoff + nzp * sizeof(F) + 15) / 16 * 16;
     const size_t off = rec.size();
     rec.resize(off + bytes, 0);
     int32_t *head = (int32_t *)(rec.data() + off);
     for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
-    head[kRecValOff] = (int32_t)valoff;
-    for (int32_t i = 0; i < rows; ++i) head[kRecSelf + i] = self_idx[(size_t)(r0 + i)];
-    memcpy(rec.data() + off + kRecHeadBytes, lcol.data() + p0, (size_t)nz * 4);
+    head[valoff_w] = (int32_t)valoff;
+    for (int32_t i = 0; i < rows; ++i) head[self_w + i] = self_idx[(size_t)(r0 + i)];
+    memcpy(rec.data() + off + head_bytes, lcol.data() + p0, (size_t)nz * 4);
     memcpy(rec.data() + off + valoff, vals + p0, (size_t)nz * sizeof(F));
-    int32_t *d = desc.data() + t * 64;
+    int32_t *d = desc.data() + t * dw;
     d[kDescCols] = D;
     d[kDescRecOff] = (int32_t)(off / 16);
     d[kDescRecChunks] = (int32_t)((bytes + 1023) / 1024);
     d[kDescRow0] = r0;
     d[kDescRows] = rows;
-    for (int32_t c = 0; c < D; ++c) d[kDescList + c] = tile_cols[(size_t)tile_ptr[t] + c];
+    const int32_t nd = (D + R - 1) / R;
+    for (int32_t c = 0; c < nd * R; ++c) d[(size_t)(c % R) * 64 + kDescList + c / R] = tile_cols[(size_t)tile_ptr[t] + std::min(c, D - 1)];
   }
-  rec.resize(rec.size() + kRingMetaBytes, 0);
+  rec.resize(rec.size() + (size_t)kRingMetaBytes * R, 0);
 }
 
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
@@ -938,11 +962,12 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     for (int x = 0; x < 9; ++x) op->tiles.xcd_tile[x] = xcd_tile[x];
     op->tiles.max_cols = mx;
     op->tiles_ringed = tiles_mode() == 2;
+    if (op->tiles_ringed) op->merged_lock = new (std::nothrow) std::mutex();
     if (te == hipSuccess && op->tiles_ringed) {
       std::vector<int32_t> desc;
       std::vector<char> rec;
-      if (dtype == SLQ_F64) build_ring_stream<double>(rowptr, (const double *)vals, tile_row, tp, tc, lc, si, desc, rec);
-      else build_ring_stream<float>(rowptr, (const float *)vals, tile_row, tp, tc, lc, si, desc, rec);
+      if (dtype == SLQ_F64) build_ring_stream<double>(1, rowptr, (const double *)vals, tile_row, tp, tc, lc, si, desc, rec);
+      else build_ring_stream<float>(1, rowptr, (const float *)vals, tile_row, tp, tc, lc, si, desc, rec);
       te = hipMalloc((void **)&op->tile_desc, desc.size() * 4);
       if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec, rec.size());
       if (te == hipSuccess) te = hipMemcpy(op->tile_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
@@ -958,8 +983,8 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         const double upper_per_row = (double)(tcu.size() - kCsrPad) / (double)n;
         if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row\n", upper_per_row);
         if (upper_per_row <= kTileAlphaColsPerRow) {
-          if (dtype == SLQ_F64) build_ring_stream<double>(urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
-          else build_ring_stream<float>(urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
+          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
+          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
           te = hipMalloc((void **)&op->tile_desc_u, desc.size() * 4);
           if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec.size());
           if (te == hipSuccess) te = hipMemcpy(op->tile_desc_u, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
@@ -1255,9 +1280,83 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->tile_rec) hipFree(op->tile_rec);
   if (op->tile_desc_u) hipFree(op->tile_desc_u);
   if (op->tile_rec_u) hipFree(op->tile_rec_u);
+  for (auto &m : op->merged) {
+    if (m.desc) hipFree(m.desc);
+    if (m.rec) hipFree(m.rec);
+    if (m.desc_u) hipFree(m.desc_u);
+    if (m.rec_u) hipFree(m.rec_u);
+  }
+  delete op->merged_lock;
   ctx_release(op->ctx);
   delete op;
   return SLQ_OK;
+}
+
+// Tiles of R = 2 or 4 merged base tiles for the narrow-panel form of the ring-fed passes (slq_ring.hpp), built the first time
+// a plan needs them and kept with the operator. A merged tile is R consecutive tiles of one XCD chunk - neighbours in the
+// sweep, so most of what they read they share - with ONE line list (build_tile_meta on the merged row ranges), hence
+// R x 14 rows, at most R x 36 lines and R x 112 nonzeros: exactly what a slot of that kernel holds. Everything comes
+// from what the operator already keeps on the device (its CSR in stored order, the tile boundaries); nothing of the
+// caller's is needed again. Returns false when the operator has no ring-sized tiles (or the build failed: the plan then
+// takes the generic passes).
+static bool ensure_ring_stream(slq_operator *op, int R) {
+  if (R == 1) return op->tile_desc != nullptr;
+  if (!op->tile_desc || !op->tiles_ringed || !op->merged_lock || (R != 2 && R != 4)) return false;
+  slq_operator::MergedStream &m = op->merged[R == 2 ? 0 : 1];
+  std::lock_guard<std::mutex> guard(*op->merged_lock);
+  if (m.tried) return m.desc != nullptr;
+  m.tried = true;
+  const int64_t n = op->n, nnz = op->nnz;
+  const size_t es = esize(op->dtype);
+  const int32_t ntiles = op->tiles.xcd_tile[8];
+  try {
+    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz), tr((size_t)ntiles + 1);
+    std::vector<char> va((size_t)nnz * es);
+    if (hipMemcpy(rp.data(), op->rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(ci.data(), op->colind, (size_t)nnz * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(va.data(), op->vals, (size_t)nnz * es, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(tr.data(), op->tiles.tile_row, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    // merged tile boundaries, chunk by chunk (a merged tile never straddles two XCD chunks; a chunk's last one may be short)
+    std::vector<int32_t> mrow;
+    for (int x = 0; x < 8; ++x) {
+      m.xcd_tile[x] = (int32_t)mrow.size();
+      for (int32_t t = op->tiles.xcd_tile[x]; t < op->tiles.xcd_tile[x + 1]; t += R) mrow.push_back(tr[(size_t)t]);
+    }
+    m.xcd_tile[8] = (int32_t)mrow.size();
+    mrow.push_back((int32_t)n);
+    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d) -> bool {
+      std::vector<int32_t> tp, tc, lc, si, desc;
+      std::vector<char> rec;
+      int mx = 0;
+      build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
+      if (mx > kRingTileCols * R) return false;  // (cannot happen: a union of R lists of <= 36)
+      if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec);
+      else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec);
+      if (hipMalloc((void **)desc_d, desc.size() * 4) != hipSuccess) return false;
+      if (hipMalloc((void **)rec_d, rec.size()) != hipSuccess) return false;
+      return hipMemcpy(*desc_d, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(*rec_d, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec);
+    if (ok && op->tile_desc_u && op->rowptr_u) {
+      const size_t nu = (size_t)op->nnz_u;
+      std::vector<int32_t> urp((size_t)n + 1), uci(nu);
+      std::vector<char> uva(nu * es);
+      ok = hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) == hipSuccess &&
+           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u);
+    }
+    if (!ok) {
+      for (void **q : {(void **)&m.desc, (void **)&m.rec, (void **)&m.desc_u, (void **)&m.rec_u}) {
+        if (*q) hipFree(*q);
+        *q = nullptr;
+      }
+    }
+    return ok;
+  } catch (const std::bad_alloc &) {
+    return false;
+  }
 }
 
 extern "C" int slq_operator_shape(const slq_operator *op, int64_t *nrows, int64_t *ncols,
@@ -1534,6 +1633,33 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     p->alpha_pad = (size_t)env_int("SLQ_ALPHA_LDS_PAD", (per_cu_env > 0 || local) ? 0 : 65536);
   }
   {
+    // which tile stream, if any (plan_tiled): wide panels take the tiles as clustered; panels of 32 / 16 lanes per row the
+    // merged tiles of the narrow-panel ring kernel (built on first use; nontemporal streams only - the one form instantiated)
+    p->ringR = 0;
+    p->ring_gen = p->ring_deep = false;
+    p->rs_desc = p->rs_desc_u = nullptr;
+    p->rs_rec = p->rs_rec_u = nullptr;
+    for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x];
+    if (op->kind == OP_CSR && op->tiles.tile_ptr && p->sw.tiles) {
+      if (p->LPR == 64) {
+        p->ringR = 1;
+        if (op->tiles_ringed) {
+          p->rs_desc = op->tile_desc, p->rs_rec = op->tile_rec, p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u;
+          p->ring_gen = p->sw.nt && env_int("SLQ_RING_GEN", 0) != 0;
+          p->ring_deep = p->sw.nt && env_int("SLQ_RING_DEEP", 1) != 0;
+        }
+      } else if ((p->LPR == 32 || p->LPR == 16) && op->tiles_ringed && p->sw.nt && env_int("SLQ_RING_NARROW", 1) != 0 &&
+                 ensure_ring_stream(op, 64 / p->LPR)) {
+        const slq_operator::MergedStream &m = op->merged[p->LPR == 32 ? 0 : 1];
+        p->ringR = 64 / p->LPR;
+        p->ring_gen = true;
+        p->ring_deep = env_int("SLQ_RING_DEEP", 1) != 0;
+        p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u;
+        for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
+      }
+    }
+  }
+  {
     // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
     // per CU and panel in the grid, panel after panel
     const int img_kib = op->tiles.tile_ptr ? (op->tiles.max_cols + 16) * (SLQ_TILE_DB ? 2 : 1) : 160;
@@ -1542,7 +1668,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     per_xcd_t = std::max(1, std::min(per_xcd_t, env_int("SLQ_TILED_WGS_PER_XCD", per_xcd_t)));  // (experiments: fewer CUs sweeping a chunk)
     if (op->tiles.tile_ptr) {
       int mn = 1 << 30;
-      for (int x = 0; x < 8; ++x) mn = std::min(mn, std::max(1, op->tiles.xcd_tile[x + 1] - op->tiles.xcd_tile[x]));
+      for (int x = 0; x < 8; ++x) mn = std::min(mn, std::max(1, p->rs_xcd[x + 1] - p->rs_xcd[x]));
       per_xcd_t = std::min(per_xcd_t, mn);
     }
     p->nblkT = 8 * per_xcd_t;
@@ -1772,6 +1898,16 @@ static int set_kernel_attributes(slq_plan *p) {
   hipError_t ae = hipSuccess;
   DISPATCH(p->dtype, p->LPR, (ae = raise_lds_limits<F, L>()));
   HIP_TRY(ae);
+  if (p->ring_gen || p->ring_deep) {
+    hipError_t re = hipSuccess;
+    const bool d = p->dtype == SLQ_F64;
+    switch (p->LPR) {
+      case 64: re = d ? slq_ring_prepare_f64_l64() : slq_ring_prepare_f32_l64(); break;
+      case 32: re = d ? slq_ring_prepare_f64_l32() : slq_ring_prepare_f32_l32(); break;
+      default: re = d ? slq_ring_prepare_f64_l16() : slq_ring_prepare_f32_l16(); break;
+    }
+    HIP_TRY(re);
+  }
   // (never from inside a stream capture: launch_dense_mfma runs under one)
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)k_dense_mfma_3term<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1780,8 +1916,8 @@ static int set_kernel_attributes(slq_plan *p) {
   return SLQ_OK;
 }
 
-// the plan's fused passes run on the operator's workgroup tiles: wide panels (one row per wave) of an operator that has them
-static bool plan_tiled(const slq_plan *p) { return p->LPR == 64 && p->op->tiles.tile_ptr != nullptr && p->sw.tiles; }
+// the plan's fused passes run on the operator's workgroup tiles (slq_plan_create decides: wide panels, and narrow ones of the ring-fed form)
+static bool plan_tiled(const slq_plan *p) { return p->ringR > 0; }
 
 // k_csr_ring_pass raises *ring_fail_d when one of its bounded waits ran out (slq_kernels.hpp: kRingSpinMax): everything the
 // plan holds is then undefined. ring_flag_status() is the flag -> status translation (no HIP call in it: a CPU test covers
@@ -2148,6 +2284,41 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
   }
 }
 
+// one ring-fed pass through k_ring_pass (slq_ring.hpp: any panel width, up to 8 ring columns; nontemporal streams)
+static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t st, int j, int xt) {
+  const bool upper = pass == PASS_ALPHA && p->rs_desc_u != nullptr && p->sw.ring_alpha == 2;
+  RingArgs a;
+  a.pass = pass;
+  a.rc = rc;
+  a.grid = grid;
+  a.st = st;
+  a.n = p->n;
+  a.desc = upper ? p->rs_desc_u : p->rs_desc;
+  a.rec = upper ? p->rs_rec_u : p->rs_rec;
+  for (int x = 0; x < 9; ++x) a.xr.first[x] = p->rs_xcd[x];
+  a.ring = p->ring;
+  a.slot_stride = p->slot_stride;
+  a.S = p->S;
+  a.j = j;
+  a.coefA = p->st.coefA;
+  a.coefB = p->st.coefB;
+  a.gamma = p->st.gamma;
+  a.part = p->part;
+  a.bpad = p->bpad;
+  a.xt = xt | ((pass == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0);
+  a.fail = p->ring_fail_d;
+  const bool d = p->dtype == SLQ_F64;
+  int rc_l = -1;
+  switch (p->LPR) {
+    case 64: rc_l = d ? slq_ring_launch_f64_l64(a) : slq_ring_launch_f32_l64(a); break;
+    case 32: rc_l = d ? slq_ring_launch_f64_l32(a) : slq_ring_launch_f32_l32(a); break;
+    case 16: rc_l = d ? slq_ring_launch_f64_l16(a) : slq_ring_launch_f32_l16(a); break;
+    default: break;
+  }
+  if (rc_l != 0) return fail(SLQ_EINVAL, "no ring-fed kernel for pass %d with %d ring columns on %d lanes per row", pass, rc, p->LPR);
+  return SLQ_OK;
+}
+
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
 static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   if (p->ring32_on && p->nstale > 0) return fail(SLQ_EINVAL, "SLQ_RING32 does not combine with preloaded stale ring columns");
@@ -2194,16 +2365,19 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       // wide panels (one row per wave) of an operator with workgroup tiles (SLQ_TILES): the tile's distinct panel rows are
       // staged once in LDS (k_csr_tile_pass); everything else about the sequence is the same
       // (ring-sized tiles serve up to kRingMaxR ring columns; steps with more take the generic passes, on the same row order)
-      const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR);
+      const bool tiled = plan_tiled(p) && !stored_u && (!op->tiles_ringed || r <= kRingMaxR || p->ring_deep);
+      const bool gen = tiled && op->tiles_ringed && (p->ring_gen || r > kRingMaxR);  // k_ring_pass rather than k_csr_ring_pass
       const size_t lds_tile = tiled ? (size_t)(SLQ_TILE_DB ? 2 : 1) * op->tiles.max_cols * p->PW * p->esz : 0;  // the tile image(s)
       // the alpha-only pass of a symmetric operator stays on the upper triangle (half the gathers) rather than the ring
       // the alpha-only pass of a symmetric operator: ring-fed over the upper-triangle stream where the operator has one
       // (SLQ_RING_ALPHA=2, default; else the generic upper-triangle pass), ring-fed over the full rows (1), generic (0)
       const bool alpha_tiled = tiled && !(op->tiles_ringed && op->rowptr_u != nullptr &&
-                                          (p->sw.ring_alpha == 0 || (p->sw.ring_alpha == 2 && op->tile_desc_u == nullptr)));
+                                          (p->sw.ring_alpha == 0 || (p->sw.ring_alpha == 2 && p->rs_desc_u == nullptr)));
 #define CSR_PASS_RC(PASS, LP, RCT, LDS, XT)                                                          \
   do {                                                                                               \
-    if (tl)                                                                                          \
+    if (tl && gen)                                                                                   \
+      SLQ_TRY(launch_ring_gen(p, PASS, RCT, gT, st, j, XT));                                         \
+    else if (tl)                                                                                     \
       DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS, LP, RCT>(p, gT, lds0 + lds_tile, st, j, XT))); \
     else                                                                                             \
       DISPATCH(p->dtype, p->LPR,                                                                     \
@@ -2271,7 +2445,8 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
     if (op->kind == OP_CSR && plan_tiled(p) && op->tiles_ringed) {
       // the sweeps' SpMM + three-term step on the ring-fed tiles (k_csr_ring_pass<PASS_SPMM>): same result slot, same alpha partials
       PROFILED(p, SLQ_K_SPMM, {
-        if (nt) DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS_SPMM, 1, 0>(p, gT, 0, st, j, 0)));
+        if (p->ring_gen) SLQ_TRY(launch_ring_gen(p, PASS_SPMM, 0, gT, st, j, 0));
+        else if (nt) DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS_SPMM, 1, 0>(p, gT, 0, st, j, 0)));
         else DISPATCH(p->dtype, p->LPR, (launch_tile_pass<F, L, PASS_SPMM, 0, 0>(p, gT, 0, st, j, 0)));
       });
       PROFILED(p, SLQ_K_FINALIZE,

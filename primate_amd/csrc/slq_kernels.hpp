@@ -17,70 +17,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "slq_common.hpp"
+
 namespace slq {
 
 #ifdef SLQ_DEBUG_TIMES
 // diagnostic build only (scripts/wave_drift.py): per-wave progress stamps of the merged dots pass
 __device__ unsigned long long *g_dbg_times = nullptr;
 #endif
-
-template <typename F> struct VecT;
-template <> struct VecT<double> {
-  typedef double type __attribute__((ext_vector_type(2)));
-  static constexpr int V = 2;
-};
-template <> struct VecT<float> {
-  typedef float type __attribute__((ext_vector_type(4)));
-  static constexpr int V = 4;
-};
-
-// ---- cache-policy helpers ---------------------------------------------------------------------
-// Streamed-once panel rows should not evict the gather window from the XCD's 4 MiB L2.
-// POLICY 0: plain; 1: nontemporal hint (global_load/store ... nt);
-// stores only, 2: write-through-and-drop (global_store ... sc1; MI355X_MICROARCH.md 'stores of each
-// flavour': sc1 stores do not keep the line in L2).
-// (Round 2 tried the other flavours on the streamed rows of the fused passes - sc1, sc0 sc1 and sc1 nt loads, sc1
-// and sc0 sc1 stores: none fetched less than nt, the sc1 loads 19 % more)
-template <int POLICY, typename VF> __device__ __forceinline__ VF stream_load(const VF *p) {
-  if (POLICY == 1) return __builtin_nontemporal_load(p);
-  return *p;
-}
-template <int POLICY, typename VF> __device__ __forceinline__ void stream_store_impl(VF *p, VF v) {
-  if (POLICY == 1) __builtin_nontemporal_store(v, p);
-  else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else *p = v;
-}
-template <int POLICY> __device__ __forceinline__ void stream_store(
-    double __attribute__((ext_vector_type(2))) * p, double __attribute__((ext_vector_type(2))) v) {
-  stream_store_impl<POLICY>(p, v);
-}
-template <int POLICY> __device__ __forceinline__ void stream_store(
-    float __attribute__((ext_vector_type(4))) * p, float __attribute__((ext_vector_type(4))) v) {
-  stream_store_impl<POLICY>(p, v);
-}
-
-constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
-constexpr int kWaves = kBlock / 64;
-constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers
-constexpr int kMaxDeg = 512;
-constexpr int kFusedMaxR = 8;        // fused recompute passes handle up to this many reorth columns
-#ifndef SLQ_UPD_UR
-#define SLQ_UPD_UR 2
-#endif         // upper bound on the Krylov degree (LDS sizing of the QL kernel)
-
-// Slot of Lanczos vector t in a ring of S slots. t may be negative: vectors "before the run" are the
-// caller's stale ring columns of the single-vector drop-in entry (slq.hip:lanczos_single), stored
-// at the far end of the ring.
-__device__ __forceinline__ int ring_slot(int t, int S) {
-  const int m = t % S;
-  return m < 0 ? m + S : m;
-}
-
-template <typename F, int LPR> struct Geo {
-  static constexpr int V = VecT<F>::V;
-  static constexpr int PW = LPR * V;   // probes per panel row
-  static constexpr int RPW = 64 / LPR; // rows per wave instruction
-};
 
 // ---- CSR row gather for wave-uniform rows (one row per wave: RPW == 1) -------------------------------
 // acc = sum_k vals[p] * X[colind[p], lane's columns] over the row's nonzeros p0 <= p < p1.
@@ -271,7 +215,6 @@ __global__ __launch_bounds__(kBlock) void k_spmm_3term(
 // i = 1..RC-1 and k_fin_adots forms alpha and the projections exactly as lanczos.h:59-63,127-135 would, up to
 // rounding. Column i = 0 (W_c itself) needs no sums: q_c.(u - alpha q_c) = alpha (1 - |q_c|^2) is pure
 // rounding of alpha - in the reference too, where it stays below the 2 eps sqrt(n) threshold - so gamma_0 = 0.
-enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3, PASS_SPMM = 4 /* ring kernel only: k_spmm_3term's job */ };
 
 template <typename F, int LPR, int PASS, int NTP, int RC, int PIPE>
 __global__ __launch_bounds__(kBlock) void k_csr_pass(
@@ -551,18 +494,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
 // of its column in its tile's list (it replaces colind in the CSR stream); `self_idx` the position of each row itself.
 // One panel row per wave instruction, i.e. LPR = 64 panels only. One workgroup per CU with TWO images (2 x 72 KiB):
 // the next tile is staged while the current one is computed. The arithmetic per row is that of k_csr_pass, products summed in CSR order.
-struct TileMeta {
-  const int32_t *tile_row;   // [ntiles + 1] first (stored) row of each tile
-  const int32_t *tile_ptr;   // [ntiles + 1] offsets into tile_cols
-  const int32_t *tile_cols;  // distinct stored row indices each tile reads, ascending (+ kCsrPad spare entries)
-  const int32_t *lcol;       // [nnz + kCsrPad] position of every nonzero's column in its tile's list
-  const int32_t *self_idx;   // [n] position of the row itself
-  int32_t xcd_tile[9];       // tiles of XCD chunk x: [xcd_tile[x], xcd_tile[x + 1])
-  int max_cols;              // longest list (LDS sizing)
-};
-struct TileRanges {
-  int32_t first[9];  // TileMeta::xcd_tile, by value in the kernel arguments
-};
 #ifndef SLQ_TILE_DB
 #define SLQ_TILE_DB 0
 #endif
@@ -770,82 +701,6 @@ __global__ __launch_bounds__(kBlock) void k_csr_tile_pass(
 //    broadcast with v_readlane), and releases the slot (done[slot] += 1).
 // Nothing but these LDS counters synchronises the waves inside the loop; every poll is bounded (kRingSpinMax, then the
 // workgroup raises *fail and leaves: the host reports the run as failed instead of hanging the GPU).
-#ifndef SLQ_RING_LOADERS
-#define SLQ_RING_LOADERS 2
-#endif
-#ifndef SLQ_RING_SLOTS
-#define SLQ_RING_SLOTS 4
-#endif
-#ifndef SLQ_RING_AUX
-#define SLQ_RING_AUX 0  // cache policy of the image DMAs (1 sc0, 2 nt, 16 sc1)
-#endif
-#ifndef SLQ_RING_LAG
-#define SLQ_RING_LAG 2
-#endif
-#ifndef SLQ_RING_GROUPS
-#define SLQ_RING_GROUPS 2
-#endif
-#ifndef SLQ_RING_CHUNK
-#define SLQ_RING_CHUNK 4
-#endif
-#ifndef SLQ_RING_WAVES
-#define SLQ_RING_WAVES 16
-#endif
-#ifndef SLQ_RING_ROWS
-#define SLQ_RING_ROWS 14
-#endif
-#ifndef SLQ_RING_COLS
-#define SLQ_RING_COLS 36
-#endif
-constexpr int kRingWaves = SLQ_RING_WAVES;  // a consumer's work per row is a chain of LDS latencies: many consumer waves hide it
-constexpr int kRingBlock = kRingWaves * 64;
-constexpr int kRingChunk = SLQ_RING_CHUNK;  // nonzeros of a row gathered per batch (power of two)
-constexpr int kRingLoaders = SLQ_RING_LOADERS;
-constexpr int kRingGroups = SLQ_RING_GROUPS;  // consumer groups taking the tiles in turn: a wave's prefetch runs kRingGroups tiles ahead
-constexpr int kRingSlots = SLQ_RING_SLOTS;
-constexpr int kRingLag = SLQ_RING_LAG;        // a loader's tiles in flight
-constexpr int kRingTileRows = SLQ_RING_ROWS;  // two rows per consumer wave of a group
-constexpr int kRingTileCols = SLQ_RING_COLS;  // distinct panel rows per tile at most
-constexpr int kRingTileNnz = 160;             // nonzeros per tile at most: the record fits kRingMetaBytes in fp64
-constexpr int kRingMetaBytes = 2048;          // 4 slots x (36 + 2) KiB + kRingHeadBytes = 156 KiB
-constexpr int kRingHeadBytes = 4096;          // flag words + the loaders' descriptor staging
-constexpr int kRingSpinMax = 1 << 20;         // ~0.1 s of polling
-constexpr int kRingMaxR = 3;                  // ring columns per step served (more: 128 VGPRs at 16 waves do not hold the sums)
-// descriptor words (tile_desc[t * 64 + ...])
-constexpr int kDescCols = 0, kDescRecOff = 1, kDescRecChunks = 2, kDescRow0 = 3, kDescRows = 4, kDescList = 8;
-// record words: [0 .. rows] row offsets into the record's own nonzeros, [15] byte offset of the values,
-// [16 .. 16 + rows) line of each row's own panel row, then from byte 128 the column lines (int32) and the values (F)
-constexpr int kRecValOff = 15, kRecSelf = 16, kRecHeadBytes = 128;
-static_assert((kRingWaves - kRingLoaders) % kRingGroups == 0 && kRingSlots % kRingGroups == 0, "every slot is served by one consumer group");
-static_assert(kRingLag < kRingSlots && kRingLoaders < kRingWaves && kRingLoaders <= 3 && kRingTileRows < kRecValOff && kRecSelf + kRingTileRows <= 32 && kRingTileCols <= 64 - kDescList, "ring geometry");
-static_assert(kRingWaves <= 16 && (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes) + kRingHeadBytes <= 160 * 1024, "ring slots must fit the LDS");
-static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes), "the final reduction reuses the slots");
-static_assert(kRecHeadBytes + ((kRingTileNnz + 3) / 4 * 4) * (4 + 8) <= kRingMetaBytes, "a tile's record must fit its slot");
-static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + 2) * kRingLag + 1 <= 63, "a loader's DMAs in flight are counted by vmcnt");
-
-// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
-__device__ __forceinline__ void wait_vmcnt_at_most(int n) {
-#define SLQ_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n < 0 ? 0 : n) {
-    SLQ_VM(0) SLQ_VM(1) SLQ_VM(2) SLQ_VM(3) SLQ_VM(4) SLQ_VM(5) SLQ_VM(6) SLQ_VM(7) SLQ_VM(8) SLQ_VM(9) SLQ_VM(10) SLQ_VM(11)
-    SLQ_VM(12) SLQ_VM(13) SLQ_VM(14) SLQ_VM(15) SLQ_VM(16) SLQ_VM(17) SLQ_VM(18) SLQ_VM(19) SLQ_VM(20) SLQ_VM(21) SLQ_VM(22)
-    SLQ_VM(23) SLQ_VM(24) SLQ_VM(25) SLQ_VM(26) SLQ_VM(27) SLQ_VM(28) SLQ_VM(29) SLQ_VM(30) SLQ_VM(31) SLQ_VM(32) SLQ_VM(33)
-    SLQ_VM(34) SLQ_VM(35) SLQ_VM(36) SLQ_VM(37) SLQ_VM(38) SLQ_VM(39) SLQ_VM(40) SLQ_VM(41) SLQ_VM(42) SLQ_VM(43) SLQ_VM(44)
-    SLQ_VM(45) SLQ_VM(46) SLQ_VM(47) SLQ_VM(48) SLQ_VM(49) SLQ_VM(50) SLQ_VM(51) SLQ_VM(52) SLQ_VM(53) SLQ_VM(54) SLQ_VM(55)
-    default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;  // a stricter wait than asked for is always safe
-  }
-#undef SLQ_VM
-}
-
-// broadcast lane `l` (wave-uniform) of a value held one entry per lane
-__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ double lane_bcast(double v, int l) {
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 template <typename F, int PASS, int NTP, int RC>
 __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
     int n, const int32_t *__restrict__ tile_desc, const char *__restrict__ tile_rec, TileRanges xr, F *ring, int64_t slot_stride, int S, int j,

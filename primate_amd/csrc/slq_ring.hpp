@@ -1,0 +1,376 @@
+// slq_ring.hpp — the ring-fed LDS-tile passes for every panel width and ring-column count.
+//
+// k_csr_ring_pass (slq_kernels.hpp) serves ONE shape: 1-KiB panel rows (128 fp64 / 256 fp32 probes per panel) and at most
+// three ring columns per step. What the reference's drivers submit is mostly something else: hutch() draws 32 probes per
+// batch (src/primate/trace.py:36,104-116), an 8-GPU shard of 256 probes is 32-64 per GPU, and orth is any number up to
+// deg (src/primate/include/lanczos.h:58-65,133-136; src/primate/lanczos.py:88-89). k_ring_pass is the same machine -
+// loader waves that land everything a tile needs in a ring of LDS slots by LDS-DMA, consumer waves behind LDS counters -
+// generalised along two axes:
+//
+//  * LPR lanes per panel row (64, 32, 16: panel rows of 1 KiB, 512 B, 256 B). R = 64 / LPR panel rows share one wave
+//    instruction: one 1-KiB DMA lands R consecutive lines of the tile image (every lane gives its own source address),
+//    and a consumer wave works on R adjacent rows of the tile at a time (lanes split rows x probe columns), so the row-
+//    local streams of a wave stay 1 KiB contiguous and an instruction moves as many bytes as in the wide kernel. The tiles
+//    of this form are R consecutive base tiles merged (one line list: what two neighbours share is landed once; slq.hip:
+//    build_ring_stream), so a slot still holds 36 KiB of image and a tile period still moves the same bytes.
+//  * WAVES = 16 (two consumer groups of 7 taking the tiles in turn, 128 VGPRs per wave: up to 3 ring columns, the
+//    row-local streams double-buffered one tile of the group ahead) or 8 (one group of 6 consumers, 256 VGPRs per wave:
+//    4..8 ring columns; a row's stream registers are refilled for the next tile as soon as the row has been consumed).
+//
+// Arithmetic per row and the order of every sum are those of k_csr_pass / k_csr_ring_pass: products of a row in CSR
+// order, rows -> waves and the final reduction over waves static. Results are reproducible bit for bit and equal to
+// the other launch sequences' up to the order of the cross-row sums.
+#pragma once
+#include "slq_common.hpp"
+
+namespace slq {
+
+constexpr int kRingRecStride = 1536;  // bytes of record per base tile: 128 B of header + kRingTileNnz x (4 + 8)
+
+template <int LPR, int WAVES> struct RingGeo {
+  static constexpr int R = 64 / LPR;                  // panel rows per wave instruction and per 1-KiB DMA
+  static constexpr int NCW = WAVES - kRingLoaders;    // consumer waves
+  static constexpr int G = WAVES >= 16 ? 2 : 1;       // consumer groups taking the tiles in turn
+  static constexpr int NC = NCW / G;                  // consumer waves of one tile
+  static constexpr int MR = (kRingTileRows + NC - 1) / NC;  // row groups (R rows each) of a tile per consumer wave
+  static constexpr int kSlots = R == 4 ? 3 : 4;       // (R = 4: four records per slot leave room for three slots)
+  static constexpr int kRecBytes = (kRingRecStride * R + 1023) / 1024 * 1024;  // landed in whole KiB
+  static constexpr int kSlotBytes = kRingTileCols * 1024 + kRecBytes;
+  static constexpr int kStageBytes = kRingLoaders * kRingLag * R * 256;  // the loaders' descriptor staging
+  static constexpr int kHeadBytes = 256 + kStageBytes;                   // flag words first
+  static constexpr int kLdsBytes = kHeadBytes + kSlots * kSlotBytes;
+  static constexpr int kDescWords = 64 * R;           // descriptor: R blocks of 64 words (block b, word 8 + d: line d * R + b)
+  static constexpr int kRecValOffW = 16 * R - 1;      // record header: [0 .. rows] row offsets, [16R - 1] byte offset of the values,
+  static constexpr int kRecSelfW = 16 * R;            //   [16R .. 16R + rows) line of each row's own panel row
+  static constexpr int kRecHeadB = 128 * R;           //   then the column lines (int32) and the values (F)
+  static_assert(WAVES == 16 || WAVES == 8, "16 waves (<= 3 ring columns) or 8 (more)");
+  static_assert(NCW % G == 0 && kRingLag < kSlots, "ring geometry");  // (a slot's counters count tiles, whichever group consumed them)
+  static_assert(kLdsBytes <= 160 * 1024, "the ring must fit the LDS");
+  static_assert(kRecHeadB + kRingTileNnz * R * (4 + 8) <= kRecBytes, "a tile's record must fit its slot");
+  static_assert(32 * R >= 16 * R + kRingTileRows * R && kRingTileRows * R < 16 * R - 1, "record header layout");
+  static_assert((size_t)WAVES * 64 * 4 * 8 <= (size_t)kSlots * kSlotBytes, "the final reduction reuses the slots");
+  static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + (kRecBytes + 1023) / 1024) * (kRingLag - 1) + R * kRingLag <= 56,
+                "a loader's DMAs in flight are counted by vmcnt");
+};
+
+template <typename F, int PASS, int NTP, int RC, int LPR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
+    int n, const int32_t *__restrict__ tile_desc, const char *__restrict__ tile_rec, TileRanges xr, F *ring, int64_t slot_stride, int S, int j,
+    const double *__restrict__ coefA, const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
+    int bpad, int xt, int *__restrict__ fail) {
+  using VF = typename VecT<F>::type;
+  using RG = RingGeo<LPR, WAVES>;
+  constexpr int R = RG::R, V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
+  constexpr int NX = RC > 2 ? RC - 2 : 1;
+  constexpr int NC = RG::NC, MR = RG::MR, G = RG::G, NS = RG::kSlots;
+  constexpr bool kRefill = G == 1;  // 8 waves: stream registers refilled in place (no second set)
+  constexpr int kChunk = R == 1 ? kRingChunk : 2;
+  static_assert(kRingLag == 2, "the descriptor staging below holds two");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  using lds_int = __attribute__((address_space(3))) int;
+  lds_int *flags = (lds_int *)lds_raw;
+  unsigned char *slots = lds_raw + RG::kHeadBytes;
+  double *red = (double *)slots;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = R == 1 ? 0 : lane / LPR, cl = R == 1 ? lane : lane % LPR;
+  const int rev = (xt >> 2) & 1;
+  const int panel = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  xt &= 1;
+  const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
+  const F *wcl = ring + (int64_t)(j % S) * slot_stride + poff;
+  const F *wp = ring + (int64_t)((j + S - 1) % S) * slot_stride + poff;
+  F *wn = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
+  const F *ux[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) ux[i] = ring + (int64_t)ring_slot(j - 2 - i, S) * slot_stride + poff;
+  if (threadIdx.x < 2 * NS + 1) flags[threadIdx.x] = 0;
+  __syncthreads();
+  lds_int *ready = flags, *done = flags + NS, *abort_f = flags + 2 * NS;
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nbl = gridDim.x >> 3;
+  const int t_first = xr.first[xcd] + bl, t_end = xr.first[xcd + 1];
+  const int ntiles = t_first < t_end ? (t_end - t_first + nbl - 1) / nbl : 0;
+  VF acc1 = (VF)(F)0, accx = (VF)(F)0;
+  VF dacc[RC > 0 ? RC : 1], gacc[RC > 0 ? RC : 1];
+#pragma unroll
+  for (int i = 0; i < (RC > 0 ? RC : 1); ++i) dacc[i] = gacc[i] = (VF)(F)0;
+  // (polls and counter updates in assembly, for the reasons given at k_csr_ring_pass: a compiler-visible LDS access in the
+  // loader would drain the DMAs that are meant to stay in flight)
+  auto spin = [&](lds_int *w, int want) -> bool {
+    for (int it = 0; it < kRingSpinMax; ++it) {
+      int have, ab;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(have), "=&v"(ab)
+                   : "v"((unsigned)(uintptr_t)w), "v"((unsigned)(uintptr_t)abort_f)
+                   : "memory");
+      if (__builtin_amdgcn_readfirstlane(have) >= want) return true;
+      if (__builtin_amdgcn_readfirstlane(ab)) return false;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(abort_f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) *fail = 1;
+    return false;
+  };
+  auto bump = [&](lds_int *w) { asm volatile("ds_add_u32 %0, %1" ::"v"((unsigned)(uintptr_t)w), "v"(1) : "memory"); };
+  auto tile_at = [&](int k) -> int64_t {  // this workgroup's k-th tile (past the end: its last one again)
+    const int kk = min(k, ntiles - 1);
+    return (int64_t)(t_first + (rev ? ntiles - 1 - kk : kk) * nbl);
+  };
+  // slot of the k-th tile and how many times that slot has been used before: the counters' targets. (NS may be 3: no
+  // power-of-two mask; the divisions are by a constant)
+  if (ntiles > 0 && wave < kRingLoaders) {
+    // ---------------- loader ----------------
+    unsigned char *stage = lds_raw + 256 + (size_t)wave * (kRingLag * R * 256);
+    auto stage_desc = [&](int k) {
+      const int32_t *src = tile_desc + tile_at(k) * RG::kDescWords + lane;
+#pragma unroll
+      for (int b = 0; b < R; ++b)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + b * 64),
+                                         (__attribute__((address_space(3))) void *)(stage + ((k & 1) * R + b) * 256), 4, 0, 0);
+    };
+    stage_desc(0);
+    int prev = 0;  // DMAs issued for tile k - 1 (the ones that may still be in flight)
+    bool ok = true;
+    for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
+      stage_desc(k + 1);
+      // descriptor k is here and tile k - 2 has landed once only what was issued after descriptor k's request is outstanding:
+      // the DMAs of tile k - 1 and the R requests of descriptor k + 1
+      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(prev + R));
+      if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % NS);
+      int issued = 0;
+      if (k < ntiles) {
+        const int slot = k % NS;
+        int dreg[R];
+#pragma unroll
+        for (int b = 0; b < R; ++b)
+          asm volatile("ds_read_b32 %0, %1" : "=&v"(dreg[b]) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + ((k & 1) * R + b) * 256) + lane * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (k >= NS) ok = spin(done + slot, NC * (k / NS));  // the slot's previous tile has been consumed
+        if (ok) {
+          unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
+          const int D = lane_bcast(dreg[0], kDescCols);
+          const int nd = (D + R - 1) / R;
+          for (int d = wave; d < nd; d += kRingLoaders) {
+            // lane group b lands line d * R + b (block b of the descriptor); past the tile's last line the descriptor repeats
+            // that line: it lands once more, in a line nobody reads (a lane's destination is fixed by its number)
+            int col = lane_bcast(dreg[0], kDescList + d);
+#pragma unroll
+            for (int b = 1; b < R; ++b) {
+              const int cb = lane_bcast(dreg[b], kDescList + d);
+              col = g == b ? cb : col;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)col * PW),
+                                             (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
+            ++issued;
+          }
+          const int chunks = lane_bcast(dreg[0], kDescRecChunks);
+          const char *rsrc = tile_rec + (int64_t)lane_bcast(dreg[0], kDescRecOff) * 16 + lane * 16;
+          for (int c = wave; c < chunks; c += kRingLoaders) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
+                                             (__attribute__((address_space(3))) void *)(img + kRingTileCols * 1024 + c * 1024), 16, 0, 0);
+            ++issued;
+          }
+        }
+      }
+      prev = issued;
+    }
+  } else if (ntiles > 0) {
+    // ---------------- consumer ----------------
+    const int cwv = wave - kRingLoaders;
+    const int grp = cwv / NC, cw = cwv % NC;  // this wave serves tiles grp, grp + G, ...
+    const int colbase = panel * PW + cl * V;
+    VF sc, cp, cb = (VF)(F)0;
+    VF gm[RC > 0 ? RC : 1];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      sc[v] = (F)coefA[colbase + v];
+      cp[v] = (F)coefA[bpad + colbase + v];
+      if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
+    }
+    if (PASS == PASS_UPDATE) {
+#pragma unroll
+      for (int i = 0; i < RC; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) gm[i][v] = (F)gamma[(int64_t)i * bpad + colbase + v];
+    }
+    auto load_desc = [&](int k) -> int { return tile_desc[tile_at(k) * RG::kDescWords + lane]; };
+    VF xpn[MR], un[MR][NX];
+    // the row-local streams (W_p, ring columns beyond W_c, W_p) of row group i of a tile, into registers
+    auto fetch_group = [&](int i, int r_lo, int nrows) {
+      const int lr = (cw + i * NC) * R + g;
+      if (lr < nrows) {
+        const int64_t ro = (int64_t)(r_lo + lr) * PW;
+        if (!first) xpn[i] = stream_load<NTP>((const VF *)(wp + ro));
+        if (PASS != PASS_ALPHA && RC > 2) {
+#pragma unroll
+          for (int q = 0; q < NX; ++q) un[i][q] = stream_load<NTP>((const VF *)(ux[q] + ro));
+        }
+      }
+    };
+    // one row group of the tile in `img`: the SpMM of the lane's row out of the image, then the pass's own arithmetic
+    auto do_group = [&](const unsigned char *img, int i, int r_lo, int nrows, const VF &xp_in, const VF *u_in) {
+      const unsigned char *rec = img + kRingTileCols * 1024;
+      const F *xl = (const F *)img + cl * V;
+      const int lr = (cw + i * NC) * R + g;
+      const bool live = lr < nrows;
+      int p0, p1, si, valoff;
+      if constexpr (R == 1) {
+        const int head = ((const int *)rec)[lane & 31];  // row offsets and own-line positions, one word per lane
+        valoff = lane_bcast(head, RG::kRecValOffW);
+        p0 = lane_bcast(head, lr);
+        p1 = lane_bcast(head, lr + 1);
+        si = lane_bcast(head, RG::kRecSelfW + lr);
+      } else {
+        const int lrc = live ? lr : nrows - 1;  // (a lane past the tile's last row walks no entries and stores nothing)
+        const int *rw = (const int *)rec;
+        p0 = rw[lrc];
+        p1 = live ? rw[lrc + 1] : p0;
+        si = rw[RG::kRecSelfW + lrc];
+        valoff = rw[RG::kRecValOffW];
+      }
+      const VF xp = first ? (VF)(F)0 : xp_in;
+      const VF xc = *(const VF *)(xl + (size_t)si * PW);
+      VF acc = (VF)(F)0;
+      if constexpr (R == 1) {
+        // entries fetched kChunk at a time by the first lanes and broadcast with v_readlane; entries past the row's end read
+        // the row's own image line with a zero coefficient, so a chunk's image reads go out back to back
+        for (int pb = p0; pb < p1; pb += kChunk) {
+          const int cnt = p1 - pb;
+          const int e = min(pb + (lane & (kChunk - 1)), p1 - 1);
+          const int lcv = *(const int *)(rec + RG::kRecHeadB + e * 4);
+          const F vav = *(const F *)(rec + valoff + e * (int)sizeof(F));
+          VF x[kChunk];
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) x[q] = *(const VF *)(xl + (size_t)(q < cnt ? lane_bcast(lcv, q) : si) * PW);
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) acc += (q < cnt ? lane_bcast(vav, q) : (F)0) * x[q];
+        }
+      } else {
+        // R rows at once: every lane reads its own row's entries (the lanes of a row read the same words: LDS broadcast)
+        for (int pb = p0; pb < p1; pb += kChunk) {
+          int lc[kChunk];
+          F va[kChunk];
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) {
+            const int e = min(pb + q, p1 - 1);
+            lc[q] = *(const int *)(rec + RG::kRecHeadB + e * 4);
+            va[q] = *(const F *)(rec + valoff + e * (int)sizeof(F));
+          }
+          VF x[kChunk];
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) x[q] = *(const VF *)(xl + (size_t)lc[q] * PW);
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) acc += (pb + q < p1 ? va[q] : (F)0) * x[q];
+        }
+      }
+      if (R == 1 || live) {
+        const int64_t ro = (int64_t)(r_lo + lr) * PW;
+        VF w = sc * acc;
+        if (!first) w -= cp * xp;
+        if (PASS == PASS_ALPHA) {
+          acc1 += (sc * xc) * w;
+        } else if (PASS == PASS_SPMM) {
+          stream_store<NTP>((VF *)(wn + ro), w);
+          acc1 += (sc * xc) * w;
+        } else if (PASS == PASS_ADOTS) {
+          acc1 += (sc * xc) * w;
+          if constexpr (RC > 1) {
+            dacc[1] += xp * w;
+            gacc[1] += xp * xc;
+          }
+#pragma unroll
+          for (int q = 2; q < RC; ++q) {
+            dacc[q] += u_in[q - 2] * w;
+            gacc[q] += u_in[q - 2] * xc;
+          }
+        } else {
+          w -= cb * xc;
+          if constexpr (RC > 0) w -= gm[0] * xc;
+          if constexpr (RC > 1) w -= gm[1] * xp;
+#pragma unroll
+          for (int q = 2; q < RC; ++q) w -= gm[q] * u_in[q - 2];
+          stream_store<NTP>((VF *)(wn + ro), w);
+          acc1 += w * w;
+          accx += w * xc;
+        }
+      }
+    };
+    int dcur = load_desc(grp), dnext = load_desc(grp + G);
+    {
+      const int r_lo0 = lane_bcast(dcur, kDescRow0), nrows0 = lane_bcast(dcur, kDescRows);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) fetch_group(i, r_lo0, nrows0);
+    }
+    bool ok = grp < ntiles;
+    for (int k = grp; k < ntiles && ok; k += G) {
+      const int slot = k % NS;
+      const int r_lo = lane_bcast(dcur, kDescRow0), nrows = lane_bcast(dcur, kDescRows);
+      const int dnext2 = load_desc(k + 2 * G);
+      const bool more = k + G < ntiles;
+      const int r_lo_n = lane_bcast(dnext, kDescRow0), nrows_n = more ? lane_bcast(dnext, kDescRows) : 0;
+      const unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
+      if constexpr (!kRefill) {
+        VF xpc[MR], uc[MR][NX];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          xpc[i] = xpn[i];
+#pragma unroll
+          for (int q = 0; q < NX; ++q) uc[i][q] = un[i][q];
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) fetch_group(i, r_lo_n, nrows_n);
+        ok = spin(ready + slot, kRingLoaders * (k / NS + 1));
+        if (!ok) break;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          if ((cw + i * NC) * R >= nrows) break;
+          do_group(img, i, r_lo, nrows, xpc[i], uc[i]);
+        }
+      } else {
+        ok = spin(ready + slot, kRingLoaders * (k / NS + 1));
+        if (!ok) break;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          if ((cw + i * NC) * R < nrows) do_group(img, i, r_lo, nrows, xpn[i], un[i]);
+          fetch_group(i, r_lo_n, nrows_n);  // the same registers, for this wave's next tile
+        }
+      }
+      // every LDS read of this wave from the slot has returned before the release
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) bump(done + slot);
+      dcur = dnext;
+      dnext = dnext2;
+    }
+  }
+  __syncthreads();
+  // partial sums of the consumer waves, column by column in wave order (loaders hold zeros), the R row groups of a wave in turn
+  const int64_t nblk = gridDim.x;
+  auto reduce_out = [&](const VF &a, double *out) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[(wave * 64 + lane) * V + v] = (double)a[v];
+    __syncthreads();
+    if ((int)threadIdx.x < PW) {
+      const int t = threadIdx.x, c = t / V, v = t % V;
+      double sum = 0.0;
+      for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+        for (int gg = 0; gg < R; ++gg) sum += red[(w * 64 + gg * LPR + c) * V + v];
+      out[t] = sum;
+    }
+    __syncthreads();
+  };
+  if (PASS == PASS_ADOTS) {
+    reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
+#pragma unroll
+    for (int i = 1; i < RC; ++i) {
+      reduce_out(dacc[i], part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
+      reduce_out(gacc[i], part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
+    }
+  } else {
+    reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
+    if (PASS == PASS_UPDATE && xt) reduce_out(accx, part + (nblk + blockIdx.x) * bpad + panel * PW);
+  }
+}
+
+}  // namespace slq

@@ -1,0 +1,35 @@
+// slq_ring_api.h — host-side entry points of the ring-fed tile passes (slq_ring.hpp). slq_ring.hip is compiled once per
+// (element type, lanes per panel row): each object defines one launcher and one attribute setter, named by its tag.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "slq_common.hpp"
+
+struct RingArgs {
+  int pass, rc;  // PASS_* of slq_kernels.hpp, ring columns of the step (compile-time variants 0..8)
+  dim3 grid;
+  hipStream_t st;
+  int n;
+  const int32_t *desc;
+  const char *rec;
+  slq::TileRanges xr;
+  void *ring;
+  int64_t slot_stride;
+  int S, j;
+  const double *coefA, *coefB, *gamma;
+  double *part;
+  int bpad, xt;
+  int *fail;
+};
+
+// launch: 0, or -1 when the object has no kernel for (pass, rc). prepare: raises the dynamic-LDS limit of all its kernels.
+#define SLQ_RING_DECLARE(TAG)                   \
+  int slq_ring_launch_##TAG(const RingArgs &a); \
+  hipError_t slq_ring_prepare_##TAG();          \
+  int slq_ring_vgprs_##TAG(int pass, int rc);
+SLQ_RING_DECLARE(f64_l64)
+SLQ_RING_DECLARE(f32_l64)
+SLQ_RING_DECLARE(f64_l32)
+SLQ_RING_DECLARE(f32_l32)
+SLQ_RING_DECLARE(f64_l16)
+SLQ_RING_DECLARE(f32_l16)

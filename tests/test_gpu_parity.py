@@ -749,6 +749,63 @@ def test_opt_in_lds_row_tiles_match_generic_passes(oracle, eng, monkeypatch, var
 	op.close()
 
 
+@pytest.mark.parametrize("case", ["lap2d_f64", "lap3d_f64", "lap3d_f32", "ragged_f64"])
+def test_ring_fed_passes_every_panel_width_and_ring_depth(oracle, eng, monkeypatch, case):
+	"""k_ring_pass (slq_ring.hpp): the ring-fed tile passes for the shapes the reference's drivers actually submit - panels
+	of 16 and 32 lanes per row (hutch's batches of 32 probes, src/primate/trace.py:36,104-116; an 8-GPU shard of 256 probes)
+	on tiles of 4 / 2 merged base tiles, and steps with 4..8 ring columns (any orth is legal, src/primate/include/lanczos.h:
+	58-65) on the 8-wave form. Per-probe values against the oracle on identical probes for P in {20, 40, 64} (+ a wide panel
+	through the same kernel, SLQ_RING_GEN=1) and orth in {0, 3, 4, 6, 8, 12}; every plan must actually be on the tiles."""
+	rng = np.random.default_rng(31)
+	monkeypatch.setenv("SLQ_TILES", "2")
+	if case == "ragged_f64":
+		## a band with random gaps and a few empty off-diagonals: ragged tiles, short last merged tile per chunk
+		n = 30011
+		offs = [1, 2, 150]
+		D = [rng.uniform(0.2, 1.0, n - o) * (rng.random(n - o) > 0.15) for o in offs]
+		B = sp.diags(D, offs, shape=(n, n))
+		A = (B + B.T + sp.diags(np.full(n, 8.0))).tocsr()
+		A.eliminate_zeros()
+		A.sort_indices()
+		tol, shapes = 1e-10, (20, 64)
+	else:
+		A = {"lap2d_f64": laplacian_2d(200), "lap3d_f64": laplacian_3d(40), "lap3d_f32": laplacian_3d(40).astype(np.float32)}[case]
+		tol = 3e-4 if A.dtype == np.float32 else 1e-10
+		shapes = (40, 100, 128) if A.dtype == np.float32 else (20, 40, 64)
+	n = A.shape[0]
+	op = eng.DeviceOperator(A)
+	for P in shapes:
+		X = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1).astype(A.dtype)
+		cols = [0, P // 2, P - 1]
+		plan = eng.LanczosPlan(op, P, 14, 3)
+		info = plan.describe()
+		plan.close()
+		assert info["tiles"] == 2 and info["panel_width"] * A.dtype.itemsize in (256, 512), info
+		for o in (0, 3, 4, 6, 8, 12):
+			ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, o, fun="log", fresh_q=True)
+			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[cols], ref, rtol=tol, err_msg=f"{case} P={P} orth={o}")
+	## wide panels: deep steps on the 8-wave form; and everything through k_ring_pass instead of k_csr_ring_pass
+	P = 300 if A.dtype == np.float32 else 130
+	X = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1).astype(A.dtype)
+	cols = [0, P // 2, P - 1]
+	refs = {o: oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, o, fun="log", fresh_q=True) for o in (0, 3, 5, 8, 12)}
+	for gen in ("0", "1"):
+		monkeypatch.setenv("SLQ_RING_GEN", gen)
+		for o, ref in refs.items():
+			np.testing.assert_allclose(eng.quad_batch(op, X, 14, o, fun="log")[cols], ref, rtol=tol, err_msg=f"{case} wide gen={gen} orth={o}")
+	monkeypatch.delenv("SLQ_RING_GEN")
+	## the switches that take the new forms out again (A/B runs): the generic passes on the tiles' row order
+	monkeypatch.setenv("SLQ_RING_DEEP", "0")
+	np.testing.assert_allclose(eng.quad_batch(op, X, 14, 6, fun="log")[cols], oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, 6, fun="log", fresh_q=True), rtol=tol)
+	monkeypatch.setenv("SLQ_RING_NARROW", "0")
+	Xn = np.asfortranarray(X[:, :40])
+	plan = eng.LanczosPlan(op, 40, 14, 3)
+	assert plan.describe()["tiles"] == 0
+	plan.close()
+	np.testing.assert_allclose(eng.quad_batch(op, Xn, 14, 3, fun="log")[:3], oracle.quad_batch(A, np.asfortranarray(Xn[:, :3]), 14, 3, fun="log", fresh_q=True), rtol=tol)
+	op.close()
+
+
 def test_tall_skinny_mfma_products(eng):
 	"""slq_dmat_gemm_tn / _nn (fp64 MFMA) against NumPy, ragged sizes on every edge."""
 	rng = np.random.default_rng(0)
