@@ -153,7 +153,7 @@ def kernel_sources_sha256():
 	import hashlib
 
 	h = hashlib.sha256()
-	for f in ("primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq.hip"):
+	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq.hip"):
 		h.update((ROOT / f).read_bytes())
 	return h.hexdigest()
 
@@ -406,8 +406,14 @@ def main():
 	default_run = args.workload == "lap2d_1000" and args.dtype == "f64" and args.orth == 3 and args.probes == 256 and args.deg == 30
 	if rank == 0 and world == 1 and default_run and not args.no_extra:
 		extra = {}
-		for key, (w, o) in {"lap3d_100_orth3": ("lap3d_100", 3), "lap3d_100_orth0": ("lap3d_100", 0), "lap2d_1000_orth0": ("lap2d_1000", 0)}.items():
-			r = measure(ctx, w, "f64", 256, 30, o, 3, 1, args.fun, 0, 1, None, red_dev, profiled=True, stream_rates=False)["line"]
+		## ... and the shapes the reference's drivers submit next to the 256-probe batch: a 64-probe panel (an 8-GPU shard of 512 probes;
+		## hutch's batches are 32, src/primate/trace.py:36) and a six-column reorthogonalisation window
+		cases = {
+			"lap3d_100_orth3": ("lap3d_100", 3, 256), "lap3d_100_orth0": ("lap3d_100", 0, 256), "lap2d_1000_orth0": ("lap2d_1000", 0, 256),
+			"lap3d_100_orth3_p64": ("lap3d_100", 3, 64), "lap2d_1000_orth3_p64": ("lap2d_1000", 3, 64), "lap2d_1000_orth6": ("lap2d_1000", 6, 256),
+		}  # fmt: skip
+		for key, (w, o, pr) in cases.items():
+			r = measure(ctx, w, "f64", pr, 30, o, 3, 1, args.fun, 0, 1, None, red_dev, profiled=True, stream_rates=False)["line"]
 			extra[key] = {
 				"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
 				"workload": r["config"]["workload"], "nnz": r["config"]["nnz"], "estimate": r["estimate"],

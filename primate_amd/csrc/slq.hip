@@ -558,8 +558,8 @@ static double sample_tile_quality(int64_t n, const int32_t *rowptr, const int32_
   return rows > 0 ? (double)cols / (double)rows : 1e9;
 }
 
-// Tile lists of the STORED CSR: per tile the ascending distinct indices of its rows and their columns, per nonzero the
-// position of its column in that list, per row the position of the row itself.
+// Tile lists of the STORED CSR: per tile the distinct indices of its rows and their columns (ascending unless SLQ_RING_ORDER
+// says otherwise), per nonzero the position of its column in that list, per row the position of the row itself.
 static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *colind, const std::vector<int32_t> &tile_row,
                             std::vector<int32_t> &tile_ptr, std::vector<int32_t> &tile_cols, std::vector<int32_t> &lcol,
                             std::vector<int32_t> &self_idx, int *max_cols) {
@@ -568,7 +568,8 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
   tile_cols.clear();
   lcol.assign((size_t)rowptr[n] + kCsrPad, 0);
   self_idx.assign((size_t)n, 0);
-  std::vector<int32_t> u;
+  std::vector<int32_t> u, pos, ordered;
+  const int line_order = env_int("SLQ_RING_ORDER", 0);
   int mx = 0;
   for (size_t t = 0; t < ntiles; ++t) {
     const int64_t r0 = tile_row[t], r1 = tile_row[t + 1];
@@ -580,12 +581,24 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
     std::sort(u.begin(), u.end());
     u.erase(std::unique(u.begin(), u.end()), u.end());
     mx = std::max(mx, (int)u.size());
-    for (int64_t r = r0; r < r1; ++r) {
-      self_idx[(size_t)r] = (int32_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin());
-      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
-        lcol[(size_t)p] = (int32_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin());
+    // position of every distinct index in the tile's list = the order its panel rows are landed in. Ascending by default;
+    // line_order 1: the tile's own rows first, then the rows below them, then the rows above (experiments, SLQ_RING_ORDER)
+    pos.resize(u.size());
+    if (line_order == 0) {
+      for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)q;
+    } else {
+      const size_t lo = (size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r0) - u.begin());
+      const size_t own = (size_t)(r1 - r0);
+      for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)(q < lo ? own + q : (q < lo + own ? q - lo : q));
     }
-    tile_cols.insert(tile_cols.end(), u.begin(), u.end());
+    ordered.resize(u.size());
+    for (size_t q = 0; q < u.size(); ++q) ordered[(size_t)pos[q]] = u[q];
+    for (int64_t r = r0; r < r1; ++r) {
+      self_idx[(size_t)r] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin())];
+      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
+        lcol[(size_t)p] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin())];
+    }
+    tile_cols.insert(tile_cols.end(), ordered.begin(), ordered.end());
     tile_ptr[t + 1] = (int32_t)tile_cols.size();
   }
   tile_cols.insert(tile_cols.end(), kCsrPad, 0);
@@ -2284,6 +2297,13 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
   }
 }
 
+#ifdef SLQ_DEBUG_TIMES
+static unsigned long long *g_dbg_host_handle = nullptr;
+static unsigned long long *debug_times_buffer() { return g_dbg_host_handle; }
+#else
+static unsigned long long *debug_times_buffer() { return nullptr; }
+#endif
+
 // one ring-fed pass through k_ring_pass (slq_ring.hpp: any panel width, up to 8 ring columns; nontemporal streams)
 static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t st, int j, int xt) {
   const bool upper = pass == PASS_ALPHA && p->rs_desc_u != nullptr && p->sw.ring_alpha == 2;
@@ -2307,6 +2327,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.bpad = p->bpad;
   a.xt = xt | ((pass == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0);
   a.fail = p->ring_fail_d;
+  a.dbg = debug_times_buffer();
   const bool d = p->dtype == SLQ_F64;
   int rc_l = -1;
   switch (p->LPR) {
@@ -3353,7 +3374,6 @@ extern "C" int slq_lanczos_f32(slq_context *ctx, slq_operator *op, float *v, int
 
 #ifdef SLQ_DEBUG_TIMES
 // Diagnostic build only (-DSLQ_DEBUG_TIMES, scripts/wave_drift.py): a device buffer of per-wave progress stamps.
-static unsigned long long *g_dbg_host_handle = nullptr;
 static size_t g_dbg_bytes = 0;
 extern "C" int slq_debug_times_begin(size_t bytes) {
   if (g_dbg_host_handle) hipFree(g_dbg_host_handle);

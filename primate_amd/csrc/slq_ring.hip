@@ -22,7 +22,7 @@ template <int PASS, int RC> constexpr int waves_of() { return RC <= kRingMaxR ? 
 template <int PASS, int RC> void launch(const RingArgs &a) {
   constexpr int W = waves_of<PASS, RC>();
   k_ring_pass<F, PASS, 1, RC, L, W><<<a.grid, dim3(W * 64), RingGeo<L, W>::kLdsBytes, a.st>>>(
-      a.n, a.desc, a.rec, a.xr, (F *)a.ring, a.slot_stride, a.S, a.j, a.coefA, a.coefB, a.gamma, a.part, a.bpad, a.xt, a.fail);
+      a.n, a.desc, a.rec, a.xr, (F *)a.ring, a.slot_stride, a.S, a.j, a.coefA, a.coefB, a.gamma, a.part, a.bpad, a.xt, a.fail, a.dbg);
 }
 template <int PASS, int RC> hipError_t prepare() {
   constexpr int W = waves_of<PASS, RC>();

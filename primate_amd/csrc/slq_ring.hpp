@@ -25,31 +25,41 @@
 
 namespace slq {
 
+#ifndef SLQ_RINGN_LOADERS
+#define SLQ_RINGN_LOADERS 2  // loader waves of k_ring_pass (A/B builds: -DSLQ_RINGN_LOADERS=4)
+#endif
+#ifndef SLQ_RINGN_PRIO
+#define SLQ_RINGN_PRIO 0     // s_setprio of the loader waves (0: none)
+#endif
+constexpr int kRingNLoaders = SLQ_RINGN_LOADERS;
 constexpr int kRingRecStride = 1536;  // bytes of record per base tile: 128 B of header + kRingTileNnz x (4 + 8)
 
 template <int LPR, int WAVES> struct RingGeo {
   static constexpr int R = 64 / LPR;                  // panel rows per wave instruction and per 1-KiB DMA
-  static constexpr int NCW = WAVES - kRingLoaders;    // consumer waves
-  static constexpr int G = WAVES >= 16 ? 2 : 1;       // consumer groups taking the tiles in turn
-  static constexpr int NC = NCW / G;                  // consumer waves of one tile
-  static constexpr int MR = (kRingTileRows + NC - 1) / NC;  // row groups (R rows each) of a tile per consumer wave
   static constexpr int kSlots = R == 4 ? 3 : 4;       // (R = 4: four records per slot leave room for three slots)
   static constexpr int kRecBytes = (kRingRecStride * R + 1023) / 1024 * 1024;  // landed in whole KiB
   static constexpr int kSlotBytes = kRingTileCols * 1024 + kRecBytes;
-  static constexpr int kStageBytes = kRingLoaders * kRingLag * R * 256;  // the loaders' descriptor staging
-  static constexpr int kHeadBytes = 256 + kStageBytes;                   // flag words first
+  static constexpr int kFlagBytes = 64;               // ready[], done[], abort
+  // loader waves: as asked for where their descriptor staging fits beside the slots, else two
+  static constexpr int kLoaders = (WAVES == 16 && kFlagBytes + kRingNLoaders * kRingLag * R * 256 + kSlots * kSlotBytes <= 160 * 1024) ? kRingNLoaders : 2;
+  static constexpr int NCW = WAVES - kLoaders;        // consumer waves
+  static constexpr int G = WAVES >= 16 ? 2 : 1;       // consumer groups taking the tiles in turn
+  static constexpr int NC = NCW / G;                  // consumer waves of one tile
+  static constexpr int MR = (kRingTileRows + NC - 1) / NC;  // row groups (R rows each) of a tile per consumer wave
+  static constexpr int kStageBytes = kLoaders * kRingLag * R * 256;  // the loaders' descriptor staging
+  static constexpr int kHeadBytes = kFlagBytes + kStageBytes;
   static constexpr int kLdsBytes = kHeadBytes + kSlots * kSlotBytes;
   static constexpr int kDescWords = 64 * R;           // descriptor: R blocks of 64 words (block b, word 8 + d: line d * R + b)
   static constexpr int kRecValOffW = 16 * R - 1;      // record header: [0 .. rows] row offsets, [16R - 1] byte offset of the values,
   static constexpr int kRecSelfW = 16 * R;            //   [16R .. 16R + rows) line of each row's own panel row
   static constexpr int kRecHeadB = 128 * R;           //   then the column lines (int32) and the values (F)
   static_assert(WAVES == 16 || WAVES == 8, "16 waves (<= 3 ring columns) or 8 (more)");
-  static_assert(NCW % G == 0 && kRingLag < kSlots, "ring geometry");  // (a slot's counters count tiles, whichever group consumed them)
+  static_assert(NCW % G == 0 && kRingLag < kSlots && (2 * kSlots + 1) * 4 <= kFlagBytes, "ring geometry");  // (a slot's counters count tiles, whichever group consumed them)
   static_assert(kLdsBytes <= 160 * 1024, "the ring must fit the LDS");
   static_assert(kRecHeadB + kRingTileNnz * R * (4 + 8) <= kRecBytes, "a tile's record must fit its slot");
   static_assert(32 * R >= 16 * R + kRingTileRows * R && kRingTileRows * R < 16 * R - 1, "record header layout");
   static_assert((size_t)WAVES * 64 * 4 * 8 <= (size_t)kSlots * kSlotBytes, "the final reduction reuses the slots");
-  static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + (kRecBytes + 1023) / 1024) * (kRingLag - 1) + R * kRingLag <= 56,
+  static_assert(((kRingTileCols + kLoaders - 1) / kLoaders + (kRecBytes + 1023) / 1024) * (kRingLag - 1) + R * kRingLag <= 56,
                 "a loader's DMAs in flight are counted by vmcnt");
 };
 
@@ -57,14 +67,14 @@ template <typename F, int PASS, int NTP, int RC, int LPR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     int n, const int32_t *__restrict__ tile_desc, const char *__restrict__ tile_rec, TileRanges xr, F *ring, int64_t slot_stride, int S, int j,
     const double *__restrict__ coefA, const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
-    int bpad, int xt, int *__restrict__ fail) {
+    int bpad, int xt, int *__restrict__ fail, unsigned long long *dbg_base /* diagnostic builds (-DSLQ_DEBUG_TIMES) only */) {
   using VF = typename VecT<F>::type;
   using RG = RingGeo<LPR, WAVES>;
   constexpr int R = RG::R, V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
   constexpr int NX = RC > 2 ? RC - 2 : 1;
   constexpr int NC = RG::NC, MR = RG::MR, G = RG::G, NS = RG::kSlots;
   constexpr bool kRefill = G == 1;  // 8 waves: stream registers refilled in place (no second set)
-  constexpr int kChunk = R == 1 ? kRingChunk : 2;
+  constexpr int kChunk = (R == 1 && WAVES == 16) ? kRingChunk : 2;  // (8 waves, R > 1: registers)
   static_assert(kRingLag == 2, "the descriptor staging below holds two");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using lds_int = __attribute__((address_space(3))) int;
@@ -119,9 +129,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
   };
   // slot of the k-th tile and how many times that slot has been used before: the counters' targets. (NS may be 3: no
   // power-of-two mask; the divisions are by a constant)
-  if (ntiles > 0 && wave < kRingLoaders) {
+  if (ntiles > 0 && wave < RG::kLoaders) {
     // ---------------- loader ----------------
-    unsigned char *stage = lds_raw + 256 + (size_t)wave * (kRingLag * R * 256);
+    if (SLQ_RINGN_PRIO) __builtin_amdgcn_s_setprio(SLQ_RINGN_PRIO);
+    unsigned char *stage = lds_raw + RG::kFlagBytes + (size_t)wave * (kRingLag * R * 256);
     auto stage_desc = [&](int k) {
       const int32_t *src = tile_desc + tile_at(k) * RG::kDescWords + lane;
 #pragma unroll
@@ -133,11 +144,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     int prev = 0;  // DMAs issued for tile k - 1 (the ones that may still be in flight)
     bool ok = true;
     for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
+#ifdef SLQ_DEBUG_TIMES
+      // (scripts/ring_timeline.py: workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles)
+      unsigned long long *dbg = (PASS == PASS_ADOTS && dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
+      if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+#endif
       stage_desc(k + 1);
       // descriptor k is here and tile k - 2 has landed once only what was issued after descriptor k's request is outstanding:
       // the DMAs of tile k - 1 and the R requests of descriptor k + 1
       wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(prev + R));
       if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % NS);
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
+#endif
       int issued = 0;
       if (k < ntiles) {
         const int slot = k % NS;
@@ -147,11 +166,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
           asm volatile("ds_read_b32 %0, %1" : "=&v"(dreg[b]) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + ((k & 1) * R + b) * 256) + lane * 4) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (k >= NS) ok = spin(done + slot, NC * (k / NS));  // the slot's previous tile has been consumed
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (ok) {
           unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
           const int D = lane_bcast(dreg[0], kDescCols);
           const int nd = (D + R - 1) / R;
-          for (int d = wave; d < nd; d += kRingLoaders) {
+          for (int d = wave; d < nd; d += RG::kLoaders) {
             // lane group b lands line d * R + b (block b of the descriptor); past the tile's last line the descriptor repeats
             // that line: it lands once more, in a line nobody reads (a lane's destination is fixed by its number)
             int col = lane_bcast(dreg[0], kDescList + d);
@@ -166,18 +188,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
           }
           const int chunks = lane_bcast(dreg[0], kDescRecChunks);
           const char *rsrc = tile_rec + (int64_t)lane_bcast(dreg[0], kDescRecOff) * 16 + lane * 16;
-          for (int c = wave; c < chunks; c += kRingLoaders) {
+          for (int c = wave; c < chunks; c += RG::kLoaders) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
                                              (__attribute__((address_space(3))) void *)(img + kRingTileCols * 1024 + c * 1024), 16, 0, 0);
             ++issued;
           }
         }
       }
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) {
+        dbg[3] = __builtin_amdgcn_s_memrealtime();
+        dbg[7] = (unsigned long long)issued;
+      }
+#endif
       prev = issued;
     }
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------
-    const int cwv = wave - kRingLoaders;
+    const int cwv = wave - RG::kLoaders;
     const int grp = cwv / NC, cw = cwv % NC;  // this wave serves tiles grp, grp + G, ...
     const int colbase = panel * PW + cl * V;
     VF sc, cp, cb = (VF)(F)0;
@@ -310,6 +338,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       const bool more = k + G < ntiles;
       const int r_lo_n = lane_bcast(dnext, kDescRow0), nrows_n = more ? lane_bcast(dnext, kDescRows) : 0;
       const unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
+#ifdef SLQ_DEBUG_TIMES
+      unsigned long long *dbg = (PASS == PASS_ADOTS && dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && cw == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
+#endif
       if constexpr (!kRefill) {
         VF xpc[MR], uc[MR][NX];
 #pragma unroll
@@ -320,16 +351,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         }
 #pragma unroll
         for (int i = 0; i < MR; ++i) fetch_group(i, r_lo_n, nrows_n);
-        ok = spin(ready + slot, kRingLoaders * (k / NS + 1));
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        ok = spin(ready + slot, RG::kLoaders * (k / NS + 1));
         if (!ok) break;
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
           if ((cw + i * NC) * R >= nrows) break;
           do_group(img, i, r_lo, nrows, xpc[i], uc[i]);
         }
       } else {
-        ok = spin(ready + slot, kRingLoaders * (k / NS + 1));
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        ok = spin(ready + slot, RG::kLoaders * (k / NS + 1));
         if (!ok) break;
+#ifdef SLQ_DEBUG_TIMES
+        if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
           if ((cw + i * NC) * R < nrows) do_group(img, i, r_lo, nrows, xpn[i], un[i]);
@@ -339,6 +382,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       // every LDS read of this wave from the slot has returned before the release
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) bump(done + slot);
+#ifdef SLQ_DEBUG_TIMES
+      if (dbg && lane == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+#endif
       dcur = dnext;
       dnext = dnext2;
     }

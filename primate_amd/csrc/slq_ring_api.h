@@ -20,6 +20,7 @@ struct RingArgs {
   double *part;
   int bpad, xt;
   int *fail;
+  unsigned long long *dbg;  // -DSLQ_DEBUG_TIMES builds: the stamp buffer (else null)
 };
 
 // launch: 0, or -1 when the object has no kernel for (pass, rc). prepare: raises the dynamic-LDS limit of all its kernels.

@@ -20,9 +20,11 @@ def eng():
 	return engine
 
 
-def test_config4_heat_kernel_diag_fp32_full_size(eng):
+def test_config4_heat_kernel_diag_fp32_full_size(eng, oracle):
 	"""configs[3]: diag(exp(-t L)) of the 126^3 7-point Laplacian, k = 50, fp32. The operator is a
-	Kronecker sum, so the exact diagonal is an outer product of 1-D heat-kernel diagonals."""
+	Kronecker sum, so the exact diagonal is an outer product of 1-D heat-kernel diagonals. The plan must be on the
+	ring-fed tiles (the default path of this operator), and two of its columns are checked against the fp32 oracle at
+	full size - quadrature and the action f(A)v - not only through statistics."""
 	m, t, k, P = 126, 0.1, 50, 128
 	A = laplacian_3d(m, dtype=np.float32)
 	assert (A.shape[0], A.nnz) == (2000376, 13907376)  # SURVEY.md §8 C4: bit-exact structure
@@ -33,9 +35,27 @@ def test_config4_heat_kernel_diag_fp32_full_size(eng):
 	op = eng.DeviceOperator(A)
 	acc = eng.DiagAccumulator(A.shape[0], ctx=op.ctx)
 	plan = eng.LanczosPlan(op, P, k, 3, keep_basis=True)
+	assert plan.describe()["tiles"] == 2 and plan.describe()["panel_width"] == 128  # 512-byte panel rows: merged tiles (slq_ring.hpp)
 	plan.generate_probes("rademacher", seed=1234)
+	V = plan.get_probes()
 	plan.run()
 	acc.update(plan, "exp", t=-t)
+	## the fp32 oracle (lanczos.h:92-149 restated, CSC product) on the first and the last column, same probes
+	cols = [0, P - 1]
+	Vc = np.asfortranarray(V[:, cols])
+	ref_q = oracle.quad_batch(A, Vc, k, 3, fun="exp", t=-t, fresh_q=True)
+	Y = plan.fun_action("exp", t=-t)
+	## ... and the action itself on the last column: ||v|| Q Y (f(theta) * Y[0, :]) from the oracle's recurrence with the
+	## whole basis kept (what MatrixFunction._matvec computes, src/primate/operators.py:113-124)
+	al, be, Q = np.zeros(k + 1, dtype=np.float32), np.zeros(k + 1, dtype=np.float32), np.zeros((A.shape[0], k), dtype=np.float32, order="F")
+	v = np.ascontiguousarray(V[:, P - 1])
+	assert oracle.lanczos(A, v.copy(), k, 1e-8, 3, al, be, Q) == k
+	th, Yv = np.linalg.eigh(np.diag(al[:k].astype(np.float64)) + np.diag(be[1:k].astype(np.float64), 1) + np.diag(be[1:k].astype(np.float64), -1))
+	ref_y = np.linalg.norm(v.astype(np.float64)) * (Q.astype(np.float64) @ (Yv @ (np.exp(-t * th) * Yv[0, :])))
+	np.testing.assert_allclose(Y[:, P - 1], ref_y, rtol=0, atol=2e-4 * np.abs(ref_y).max())
+	del Q
+	np.testing.assert_allclose(np.einsum("ij,ij->j", V[:, cols].astype(np.float64), Y[:, cols].astype(np.float64)), ref_q, rtol=3e-4)
+	del V, Y
 	numer, denom, rmean, cnt = acc.get()
 	assert cnt == P and np.all(denom == P)  # Rademacher: v*v = 1 exactly, P times
 	est = numer / denom
@@ -44,7 +64,9 @@ def test_config4_heat_kernel_diag_fp32_full_size(eng):
 	plan2 = eng.LanczosPlan(op, P, k, 3)
 	plan2.generate_probes("rademacher", seed=1234)
 	plan2.run()
+	assert plan2.describe()["tiles"] == 2
 	q = plan2.quadrature("exp", t=-t)
+	np.testing.assert_allclose(q[cols], ref_q, rtol=3e-4)  # the quadrature path against the oracle, per probe
 	assert abs(numer.sum() / P - q.mean()) < 2e-4 * abs(q.mean())  # v^T f(A) v by action vs by quadrature (fp32)
 	assert abs(q.mean() - exact.sum()) < 6 * q.std(ddof=1) / np.sqrt(P)
 

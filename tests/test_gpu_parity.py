@@ -428,6 +428,21 @@ def test_full_size_properties_c2(eng, oracle):
 	p0.generate_probes("rademacher", seed=1234)
 	p0.run()
 	np.testing.assert_allclose(p0.quadrature("log"), q_all[:16], rtol=1e-10)
+	## deeper windows (4..6 ring columns per step: the 8-wave ring-fed form) and the narrow panels the reference's drivers
+	## submit (hutch's batch of 32, an 8-GPU shard of 64; merged tiles), at full size: the oracle on two columns each
+	V = None
+	for P, orth in ((256, 6), (64, 3), (64, 6), (32, 3)):
+		pl = eng.LanczosPlan(op, P, 30, orth)
+		assert pl.describe()["tiles"] == 2, (P, orth)
+		pl.generate_probes("rademacher", seed=1234)
+		if V is None:
+			V = pl.get_probes()
+		pl.run()
+		qd = pl.quadrature("log")
+		pl.close()
+		cc = [0, P - 1]
+		ref = oracle.quad_batch(L2, np.asfortranarray(V[:, cc]), 30, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(qd[cc], ref, rtol=1e-10, err_msg=f"P={P} orth={orth}")
 
 
 def test_full_size_north_star_operator_on_the_default_path(eng, oracle):
