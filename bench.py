@@ -324,8 +324,10 @@ def spawn_ranks(n, argv, cmd=None, timeout=None):
 			except subprocess.TimeoutExpired:
 				p.kill()
 				p.wait()
-	sys.stdout.write(out0.decode(errors="replace"))
-	sys.stdout.flush()
+	## stdout stays ONE line: rank 0's JSON record. Anything else a rank-0 library printed there (gloo announces its peers on
+	## stdout) is passed on through stderr
+	for ln in out0.decode(errors="replace").splitlines():
+		print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
 	codes = [p.returncode for p in procs]
 	bad = [c for c in codes if c != 0]
 	if bad:

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -218,6 +219,18 @@ static int env_int(const char *name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 static int tiles_mode() { return env_int("SLQ_TILES", kTilesDefault); }
+
+// wall time of the phases of an operator's creation, printed under SLQ_DEBUG (scripts/time_create.py)
+struct PhaseClock {
+  bool on = env_int("SLQ_DEBUG", 0) != 0;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[slq] create: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -711,6 +724,8 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     if (colind[p] < 0 || colind[p] >= n)
       return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[p], (long long)p);
   HIP_TRY(hipSetDevice(ctx->device));
+  PhaseClock clk;
+  clk.lap("validation");
   if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
@@ -763,6 +778,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: sample of 256 clusters: %.2f distinct panel rows per row\n", q);
     if (q > 1.25 * kTileMaxColsPerRow) try_tiles = false;
   }
+  clk.lap("tile sample");
   const double tile_limit = kTileMaxColsPerRow;
   std::vector<int32_t> tile_row;
   int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -829,6 +845,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       rcm_perm.clear();  // declined: the generic passes keep their own (one-piece) order, decided below
     }
   }
+  clk.lap("base order + clusters");
   bool want = false;
   if (nnz > 0 && !have_tiles) {
     if (reorder_mode == 2) want = true;
@@ -864,6 +881,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     op->rms_dist = mean_dist(&inv);
   }
   if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
+  clk.lap("reorder decision");
   if (op->perm_h) {
     std::vector<int32_t> &perm = *op->perm_h;
     std::vector<int32_t> inv((size_t)n);
@@ -896,6 +914,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);  // (inv is a local)
     if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
   }
+  clk.lap("permuted CSR");
   {
     // gathers per row that reach further than any cache-resident halo (|i - j| > 4096 rows in the stored
     // order): what decides between the recompute passes and the store-and-revisit sweeps (enqueue_run)
@@ -922,6 +941,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     slq_operator_destroy(op);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
   }
+  clk.lap("far count + CSR upload");
   // Symmetric operators (what Lanczos assumes; the reference never checks): the alpha pass only needs the
   // scalar q^T A q, so it can run on the upper triangle with doubled off-diagonals and gather half the
   // panel rows. Built only when the stored CSR is EXACTLY symmetric (pattern and values, sorted rows
@@ -950,6 +970,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       }
     }
   }
+  clk.lap("upper triangle");
   // workgroup tiles (SLQ_TILES): lists of the stored CSR, uploaded next to it
   if (have_tiles) {
     std::vector<int32_t> tp, tc, lc, si;
@@ -1010,6 +1031,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile upload: %s", hipGetErrorString(te));
     }
   }
+  clk.lap("tile lists + streams");
   *out = op;
   return SLQ_OK;
 }

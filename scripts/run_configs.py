@@ -1,7 +1,7 @@
 """Full-size runs of BASELINE.json configs[2]-[4] on ONE GPU: wall time, probe-matvecs/s, and for the Lanczos loop of
 each the per-kernel roofline (HIP events on the library's stream, the same algorithmic-byte model as bench.py).
 
-    python scripts/run_configs.py [c3 c3x c4 c5 ...]   ->  gpurun_out/r02_configs.json  (copied to profiles/ when judged)
+    python scripts/run_configs.py [c3 c3x c4 c5 ...]   ->  gpurun_out/r03_configs.json  (copied to profiles/ when judged)
 
 c3  = configs[2] operator, hutch (quadrature) at orth 0 and 3          c3x = configs[2] as worded: xtrace, 512 vectors
 c4  = configs[3]: diag(exp(-t L)), 126^3 7-point grid, fp32, k = 50, 1024 probes
@@ -25,7 +25,7 @@ from conftest import laplacian_3d  # noqa: E402
 from primate_amd.engine import DeviceOperator, DiagAccumulator, LanczosPlan  # noqa: E402
 
 which = sys.argv[1:] or ["c3", "c3x", "c4", "c5"]
-out_path = ROOT / "gpurun_out" / "r02_configs.json"
+out_path = ROOT / "gpurun_out" / "r03_configs.json"
 out = json.loads(out_path.read_text()) if out_path.exists() else {}
 out["_meta"] = {"kernel_sha256": bench.kernel_sources_sha256(), "peak_GBps": bench.HBM_PEAK_GBS,
                 "note": "per-kernel ms are HIP events on the library's stream over the timed batches; alg_GBps = bench.kernel_bytes / ms"}  # fmt: skip
@@ -83,8 +83,18 @@ if "c3" in which:
 			qs.append(plan.quadrature("exp"))
 		dt = time.time() - t0
 		q = np.concatenate(qs)
+		roof = lanczos_roofline(plan, W, B, k, orth, P // B)
+		## gather-aware bound: on G(n, p) every stored nonzero is an L2 miss - its panel row (panel width x 8 B) comes from
+		## HBM - so a gathering launch moves nnz x row bytes per panel next to its algorithmic bytes; MI355X_MICROARCH.md gives
+		## 7.4-7.9 TB/s for random whole rows of a table this size (Indexed rows: gather into LDS), 7.65 used here
+		pw = roof["plan"]["panel_width"]
+		gather = float(W.nnz) * pw * 8 * (B // pw)
+		for kname, row in roof["kernels"].items():
+			if kname in ("spmm_3term", "reorth_dot") and "alg_GB_per_launch" in row and (kname == "spmm_3term" or roof["plan"]["sequence"] == "fused_stored_u"):
+				ms = row["ms_per_batch"] / row["launches_per_batch"]
+				row.update(gather_bytes_per_launch=int(gather), gather_GBps=round(gather / (ms * 1e-3) / 1e9, 1), frac_of_gather_bound=round(gather / (ms * 1e-3) / 1e9 / 7650.0, 4))
 		res[f"hutch_orth{orth}"] = dict(seconds=round(dt, 4), probe_matvecs_per_s=round(P * k / dt, 1), estimate=float(q.mean()),
-		                                stderr=float(q.std(ddof=1) / np.sqrt(P)), **lanczos_roofline(plan, W, B, k, orth, P // B))  # fmt: skip
+		                                stderr=float(q.std(ddof=1) / np.sqrt(P)), **roof)  # fmt: skip
 		plan.close()
 	out["configs[2]_hutch"] = res
 	print(json.dumps({"c3": res}), flush=True)
@@ -142,34 +152,42 @@ if "c4" in which:
 	op.close()
 
 if "c5" in which:
-	## one GPU's share of configs[4]: 2048 probes / 8 GPUs = 256 probes, in batches of as many as the ring admits
+	## one GPU's share of configs[4] as worded - eigencount by the step function, full reorthogonalisation: 2048 probes / 8 GPUs
+	## = 256 probes, in batches of as many as the ring admits. The operator is the symmetric circulant band of
+	## tests/test_gpu_fullsize.py (15 per row, closed-form spectrum), the cut its median: the count is known exactly.
+	## C5_RING32=1 runs the opt-in fp32 archive of finished vectors: twice the probes per batch.
+	from test_gpu_fullsize import circulant_band
+
 	n, k, share = 10_000_000, 80, int(os.environ.get("C5_PROBES", 256))
-	B = int(os.environ.get("C5_BATCH", 32))  # 81 ring slots x n x 32 x 8 B = 207 GB of the 288 GB
-	rng = np.random.default_rng(1234)
-	offs = np.unique(np.concatenate([[1, 2, 3], rng.integers(4, 2000, 4)]))[:7]
-	S = sp.diags([rng.uniform(-1, 0, n - o) for o in offs], offs, shape=(n, n))
-	S = (S + S.T).tocsr()
-	d = np.asarray(abs(S).sum(axis=1)).ravel() * rng.uniform(0.2, 1.2, n)  # not all rows dominant: indefinite tail
-	A = (S + sp.diags(d)).tocsr()
-	A.sort_indices()
+	A, lam = circulant_band(n)
+	cut = float(np.median(lam)) + 1e-3
+	exact = int(np.count_nonzero(lam >= cut))
+	del lam
 	op = DeviceOperator(A)
-	plan = LanczosPlan(op, B, k, k)
-	plan.profile_enable(True)
-	plan.profile_read(reset=True)
-	qs = []
-	op.ctx.synchronize()
-	t0 = time.time()
-	for c in range(0, share, B):
-		plan.generate_probes("rademacher", seed=1234, probe_offset=c)
-		plan.run()
-		qs.append(plan.quadrature("numrank", threshold=1e-6))
-		print(f"c5 batch at probe {c}: {time.time() - t0:.1f} s", flush=True)
-	dt = time.time() - t0
-	q = np.concatenate(qs)
-	out["configs[4]_one_gpu_share"] = dict(n=n, nnz=int(A.nnz), k=k, probes=share, batch=B, orth=k, seconds=round(dt, 3), probe_matvecs_per_s=round(share * k / dt, 1),
-	                                       eigencount=float(q.mean()), stderr=float(q.std(ddof=1) / np.sqrt(share)), **lanczos_roofline(plan, A, B, k, k, share // B))  # fmt: skip
-	print(json.dumps({"c5": out["configs[4]_one_gpu_share"]}), flush=True)
-	plan.close()
+	for ring32 in ([0, 1] if os.environ.get("C5_RING32", "both") == "both" else [int(os.environ["C5_RING32"])]):
+		B = int(os.environ.get("C5_BATCH", 64 if ring32 else 32))  # 81 ring slots x n x 32 x 8 B = 207 GB of the 288 GB
+		if ring32:
+			os.environ["SLQ_RING32"] = "1"
+		plan = LanczosPlan(op, B, k, k)
+		plan.profile_enable(True)
+		plan.profile_read(reset=True)
+		qs = []
+		op.ctx.synchronize()
+		t0 = time.time()
+		for c in range(0, share, B):
+			plan.generate_probes("rademacher", seed=1234, probe_offset=c)
+			plan.run()
+			qs.append(plan.quadrature("step", c=cut))
+			print(f"c5 ring32={ring32} batch at probe {c}: {time.time() - t0:.1f} s", flush=True)
+		dt = time.time() - t0
+		q = np.concatenate(qs)
+		key = "configs[4]_one_gpu_share" + ("_ring32" if ring32 else "")
+		out[key] = dict(n=n, nnz=int(A.nnz), k=k, probes=share, batch=B, orth=k, fun=f"step(c={cut:.6f})", seconds=round(dt, 3), probe_matvecs_per_s=round(share * k / dt, 1),
+		                eigencount=float(q.mean()), exact_count=exact, rel_err=float(q.mean() / exact - 1), stderr=float(q.std(ddof=1) / np.sqrt(share)),
+		                **lanczos_roofline(plan, A, B, k, k, share // B))  # fmt: skip
+		print(json.dumps({"c5": out[key]}), flush=True)
+		plan.close()
+		os.environ.pop("SLQ_RING32", None)
 	op.close()
 
 out_path.parent.mkdir(exist_ok=True)

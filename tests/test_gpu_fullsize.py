@@ -23,7 +23,7 @@ def eng():
 def test_config4_heat_kernel_diag_fp32_full_size(eng, oracle):
 	"""configs[3]: diag(exp(-t L)) of the 126^3 7-point Laplacian, k = 50, fp32. The operator is a
 	Kronecker sum, so the exact diagonal is an outer product of 1-D heat-kernel diagonals. The plan must be on the
-	ring-fed tiles (the default path of this operator), and two of its columns are checked against the fp32 oracle at
+	ring-fed tiles (the default path of this operator), and two of its columns are checked against the oracle at
 	full size - quadrature and the action f(A)v - not only through statistics."""
 	m, t, k, P = 126, 0.1, 50, 128
 	A = laplacian_3d(m, dtype=np.float32)
@@ -40,21 +40,26 @@ def test_config4_heat_kernel_diag_fp32_full_size(eng, oracle):
 	V = plan.get_probes()
 	plan.run()
 	acc.update(plan, "exp", t=-t)
-	## the fp32 oracle (lanczos.h:92-149 restated, CSC product) on the first and the last column, same probes
+	## the oracle on the first and the last column, same probes - run in fp64 on the same (exactly representable) operator and
+	## probes: at n = 2e6 the fp32 oracle is the noisier of the two implementations (its reductions are one sequential fp32
+	## accumulator: 0.7 % off on this column, basis orthogonal to 7e-3, against 3e-6 for the device's blocked sums -
+	## scripts/check_c4_action.py), so the exact-arithmetic value of the same recurrence is the yardstick for fp32 here; the
+	## fp32-vs-fp32 comparison stays at 40^3 (test_gpu_parity.py)
 	cols = [0, P - 1]
-	Vc = np.asfortranarray(V[:, cols])
-	ref_q = oracle.quad_batch(A, Vc, k, 3, fun="exp", t=-t, fresh_q=True)
+	A64 = A.astype(np.float64)
+	Vc = np.asfortranarray(V[:, cols].astype(np.float64))
+	ref_q = oracle.quad_batch(A64, Vc, k, 3, fun="exp", t=-t, fresh_q=True)
 	Y = plan.fun_action("exp", t=-t)
 	## ... and the action itself on the last column: ||v|| Q Y (f(theta) * Y[0, :]) from the oracle's recurrence with the
 	## whole basis kept (what MatrixFunction._matvec computes, src/primate/operators.py:113-124)
-	al, be, Q = np.zeros(k + 1, dtype=np.float32), np.zeros(k + 1, dtype=np.float32), np.zeros((A.shape[0], k), dtype=np.float32, order="F")
-	v = np.ascontiguousarray(V[:, P - 1])
-	assert oracle.lanczos(A, v.copy(), k, 1e-8, 3, al, be, Q) == k
-	th, Yv = np.linalg.eigh(np.diag(al[:k].astype(np.float64)) + np.diag(be[1:k].astype(np.float64), 1) + np.diag(be[1:k].astype(np.float64), -1))
-	ref_y = np.linalg.norm(v.astype(np.float64)) * (Q.astype(np.float64) @ (Yv @ (np.exp(-t * th) * Yv[0, :])))
+	al, be, Q = np.zeros(k + 1), np.zeros(k + 1), np.zeros((A.shape[0], k), order="F")
+	v = np.ascontiguousarray(Vc[:, 1])
+	assert oracle.lanczos(A64, v.copy(), k, 1e-8, 3, al, be, Q) == k
+	th, Yv = np.linalg.eigh(np.diag(al[:k]) + np.diag(be[1:k], 1) + np.diag(be[1:k], -1))
+	ref_y = np.linalg.norm(v) * (Q @ (Yv @ (np.exp(-t * th) * Yv[0, :])))
 	np.testing.assert_allclose(Y[:, P - 1], ref_y, rtol=0, atol=2e-4 * np.abs(ref_y).max())
 	del Q
-	np.testing.assert_allclose(np.einsum("ij,ij->j", V[:, cols].astype(np.float64), Y[:, cols].astype(np.float64)), ref_q, rtol=3e-4)
+	np.testing.assert_allclose(np.einsum("ij,ij->j", Vc, Y[:, cols].astype(np.float64)), ref_q, rtol=3e-4)
 	del V, Y
 	numer, denom, rmean, cnt = acc.get()
 	assert cnt == P and np.all(denom == P)  # Rademacher: v*v = 1 exactly, P times
@@ -174,29 +179,62 @@ def eng_quad_identity(plan, op, P, k, orth):
 	return plan.quadrature("identity")
 
 
-def test_config5_full_reorth_n1e7(eng):
-	"""configs[4] (one GPU's slice, 8 probes): n = 1e7 banded SPD CSR, k = 80, full reorthogonalisation
-	(81 ring slots resident = 104 GB). Full reorth and no reorth give the same Gauss rule sums."""
-	n, k, P = 10_000_000, 80, 8
-	rng = np.random.default_rng(1234)
-	offs = [1, 2, 3, 57, 411, 977, 1993]
-	S = sp.diags([rng.uniform(-1, 0, n - o) for o in offs], offs, shape=(n, n))
-	S = (S + S.T).tocsr()
-	A = (S + sp.diags(np.asarray(abs(S).sum(axis=1)).ravel() + 0.1)).tocsr()
-	A.sort_indices()
-	assert A.shape[0] == n and A.nnz == n + 2 * sum(n - o for o in offs)
+def circulant_band(n, offs=(1, 2, 3, 57, 411, 977, 1993), weights=(1.0, 0.85, 0.7, 0.9, 0.6, 0.75, 0.8), shift=0.1):
+	"""Symmetric circulant band matrix with 2 len(offs) + 1 nonzeros per row (BASELINE.json configs[4]: n = 1e7, 15 per row):
+	A[i, (i +- o) mod n] = -w_o, A[i, i] = 2 sum(w) + shift. Its eigenvalues are known in closed form,
+	lambda_k = d - 2 sum_o w_o cos(2 pi k o / n), so the number of eigenvalues above any cut is exact. Returns (A, lambda)."""
+	offs, w = np.asarray(offs), np.asarray(weights, dtype=np.float64)
+	d = 2.0 * w.sum() + shift
+	rel = np.concatenate([-offs[::-1], [0], offs])  # ascending relative columns
+	val = np.concatenate([-w[::-1], [d], -w])
+	indices = ((np.arange(n, dtype=np.int64)[:, None] + rel[None, :]) % n).astype(np.int32)
+	data = np.broadcast_to(val, (n, len(rel))).copy()
+	wrap = np.concatenate([np.arange(offs.max()), np.arange(n - offs.max(), n)])  # rows whose columns wrap around: sort them
+	order = np.argsort(indices[wrap], axis=1)
+	indices[wrap] = np.take_along_axis(indices[wrap], order, axis=1)
+	data[wrap] = np.take_along_axis(data[wrap], order, axis=1)
+	A = sp.csr_matrix((data.ravel(), indices.ravel(), np.arange(0, n * len(rel) + 1, len(rel), dtype=np.int32)), shape=(n, n))
+	A.has_sorted_indices = True
+	k = np.arange(n, dtype=np.float64)
+	lam = np.full(n, d)
+	for o, wo in zip(offs, w):
+		lam -= 2.0 * wo * np.cos(2.0 * np.pi * ((k * o) % n) / n)
+	return A, lam
+
+
+def test_config5_eigencount_by_step_function_full_reorth_n1e7(eng):
+	"""configs[4] as BASELINE.json words it: eigencount via the step function (src/primate/special.py:69-74) on an n = 1e7
+	CSR with 15 nonzeros per row, k = 80, full reorthogonalisation (81 ring slots x 32 probes resident = 207 GB), one
+	batch of one GPU's share of the 2048 probes. The operator is a symmetric circulant band, so the count of eigenvalues
+	above a cut INSIDE the spectrum is known exactly: the estimate must lie within 3 standard errors plus the quadrature's
+	own uncertainty - the Gauss weights of the two nodes next to the cut bracket the spectral measure there
+	(Chebyshev-Markov-Stieltjes) - of it. Full and no reorthogonalisation give the same smooth-function rule sums."""
+	n, k, P = 10_000_000, 80, 32
+	A, lam = circulant_band(n)
+	assert A.shape[0] == n and A.nnz == 15 * n and np.all(np.diff(A.indptr) == 15)
+	cut = float(np.median(lam)) + 1e-3  # strictly inside the spectrum, on no eigenvalue cluster's edge
+	exact = int(np.count_nonzero(lam >= cut))
+	assert 0.4 * n < exact < 0.6 * n and lam.min() > 0.09
 	op = eng.DeviceOperator(A)
 	out = {}
-	for orth in (k, 0):
-		plan = eng.LanczosPlan(op, P, k, orth)
+	for orth, probes in ((k, P), (0, 8)):
+		plan = eng.LanczosPlan(op, probes, k, orth)
 		if orth == k:
-			assert plan.workspace_bytes > 100e9
+			assert plan.workspace_bytes > 200e9
 		plan.generate_probes("rademacher", seed=7)
 		plan.run()
 		q, nodes, weights = plan.quadrature("log", return_rule=True)
 		np.testing.assert_allclose(weights.sum(axis=1), 1.0, atol=1e-12)
-		assert nodes.min() > 0.09  # Gershgorin: diagonally dominant by 0.1
-		out[orth] = (q, plan.quadrature("numrank"))
+		assert nodes.min() > 0.09 and nodes.max() < lam.max() + 1e-9  # Ritz values inside the spectrum
+		out[orth] = (q, plan.quadrature("step", c=cut), nodes, weights)
+		np.testing.assert_allclose(plan.quadrature("numrank"), n, rtol=1e-12)  # all of the spectrum above 1e-6: that cut counts everything
 		plan.close()
-	np.testing.assert_allclose(out[k][0], out[0][0], rtol=1e-9)
-	np.testing.assert_allclose(out[k][1], n, rtol=1e-12)  # every Ritz value > 1e-6: full numerical rank
+	np.testing.assert_allclose(out[k][0][:8], out[0][0], rtol=1e-9)
+	counts, nodes, weights = out[k][1], out[k][2], out[k][3]
+	est, stderr = counts.mean(), counts.std(ddof=1) / np.sqrt(P)
+	## per probe: the two nodes next to the cut; the measure of [cut, inf) lies within their weights of the rule's sum
+	j = np.array([np.searchsorted(nodes[i], cut) for i in range(P)])
+	bracket = np.array([weights[i, max(j[i] - 1, 0)] + weights[i, min(j[i], k - 1)] for i in range(P)]) * n
+	assert abs(est - exact) < 3 * stderr + bracket.mean(), (est, exact, stderr, bracket.mean())
+	assert abs(est / exact - 1) < 0.05
+	assert stderr < 0.01 * n  # full reorthogonalisation: the per-probe counts scatter by well under a per cent of n

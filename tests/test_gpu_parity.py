@@ -127,6 +127,25 @@ def test_c2_anchor_full_size(golden, eng):
 		assert abs(q[0] / golden["c2_quad_log_seed1234_o0_o3"][k] - 1) < 1e-10
 
 
+def test_step_function_with_a_cut_inside_the_spectrum(oracle, eng, lap):
+	"""f = step(c) (src/primate/special.py:69-74; numrank is step(1e-6, nonnegative=True), :103-105) with the cut INSIDE the
+	spectrum, where it actually removes Ritz values: per-probe sums against the oracle, both senses of `nonnegative`, and
+	the counting identity sum f(theta) tau = sum of the weights of the nodes at or above the cut."""
+	L, op, V = lap
+	for orth in (0, 3, 20):
+		for kw in ({"c": 3.9173}, {"c": 1.2345, "nonnegative": True}, {"c": 7.5}):
+			got = eng.quad_batch(op, V, 20, orth, fun="step", **kw)
+			ref = oracle.quad_batch(L, V, 20, orth, fun="step", fresh_q=True, **kw)
+			np.testing.assert_allclose(got, ref, rtol=1e-10, err_msg=f"orth={orth} {kw}")
+		plan = eng.LanczosPlan(op, V.shape[1], 20, orth)
+		plan.set_probes(V)
+		plan.run()
+		q, nodes, weights = plan.quadrature("step", return_rule=True, c=3.9173)
+		np.testing.assert_allclose(q, (weights * (nodes >= 3.9173)).sum(axis=1) * (V * V).sum(axis=0), rtol=1e-12)
+		assert np.all(q > 0) and np.all(q < (V * V).sum(axis=0))  # the cut bites: neither nothing nor everything is counted
+		plan.close()
+
+
 @pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-10), (np.float32, 3e-4)])
 @pytest.mark.parametrize("orth", [0, 3, 25])
 def test_oracle_random_graph_ragged(oracle, eng, dtype, rtol, orth):

@@ -300,16 +300,16 @@ def test_bench_starts_its_own_ranks(capfd):
 	children here are stubs - no torch, no GPU."""
 	import bench
 
-	stub = "import os, sys; r = int(os.environ['RANK']); print('line', r, os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], bool(int(os.environ['MASTER_PORT']))); sys.exit(int(sys.argv[1]) if r == int(sys.argv[2]) else 0)"
+	stub = "import os, sys; r = int(os.environ['RANK']); print('[lib] chatter on stdout'); print('{line', r, os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'], bool(int(os.environ['MASTER_PORT']))); sys.exit(int(sys.argv[1]) if r == int(sys.argv[2]) else 0)"
 	rc = bench.spawn_ranks(3, ["0", "0"], cmd=[sys.executable, "-c", stub])
 	out, err = capfd.readouterr()
-	assert rc == 0 and out == "line 0 0 3 127.0.0.1 True\n"  # rank 0's line and nothing else on stdout
-	assert "line 1 1 3" in err and "line 2 2 3" in err
+	assert rc == 0 and out == "{line 0 0 3 127.0.0.1 True\n"  # rank 0's record and nothing else on stdout
+	assert "line 1 1 3" in err and "line 2 2 3" in err and "[lib] chatter" in err
 	rc = bench.spawn_ranks(2, ["5", "1"], cmd=[sys.executable, "-c", stub])  # rank 1 fails with 5
 	out, err = capfd.readouterr()
-	assert rc == 5 and out.startswith("line 0 0 2") and "exit codes [0, 5]" in err
+	assert rc == 5 and out.startswith("{line 0 0 2") and "exit codes [0, 5]" in err
 	## a rank that hangs is ended by the parent (its own child, by handle), the others' result is kept
-	hang = "import os, sys, time; r = int(os.environ['RANK']); print('up', r, flush=True); time.sleep(600 if r == 1 else 0)"
+	hang = "import os, sys, time; r = int(os.environ['RANK']); print('{up', r, flush=True); time.sleep(600 if r == 1 else 0)"
 	rc = bench.spawn_ranks(2, [], cmd=[sys.executable, "-c", hang], timeout=3)
 	out, err = capfd.readouterr()
-	assert rc != 0 and out == "up 0\n"
+	assert rc != 0 and out == "{up 0\n"
