@@ -15,6 +15,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -66,10 +67,20 @@ struct slq_context {
   // becomes unusable for NEW objects; its stream lives until the last dependant has been destroyed.
   int refs = 0;
   bool dead = false;
+  // pinned staging ring for host -> device uploads of probes (slq_plan_set_probes): two buffers, so that the host-side copy
+  // of one chunk runs while the previous chunk is on its way over PCIe
+  void *pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_busy[2] = {false, false};
+  size_t pin_bytes = 0;
 };
 static void ctx_retain(slq_context *ctx) { ++ctx->refs; }
 static void ctx_free(slq_context *ctx) {
   hipSetDevice(ctx->device);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->pin[b]) hipHostFree(ctx->pin[b]);
+    if (ctx->pin_ev[b]) hipEventDestroy(ctx->pin_ev[b]);
+  }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -220,6 +231,38 @@ static int env_int(const char *name, int dflt) {
 }
 static int tiles_mode() { return env_int("SLQ_TILES", kTilesDefault); }
 
+// Host-side work of an operator's creation (row orders, clusters, tile lists, streams) is cut into independent pieces -
+// XCD chunks, tile ranges, row ranges - and run on a few threads: fn(piece, begin, end) over [0, count). Results never depend
+// on the number of threads (every piece writes its own slots or its own buffer, joined in piece order). SLQ_HOST_THREADS
+// overrides the default of min(8, hardware threads). Exceptions do not leave a worker: the first failure is reported.
+static int host_threads() {
+  const int hw = (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(64, env_int("SLQ_HOST_THREADS", std::max(1, std::min(8, hw)))));
+}
+template <typename Fn> static bool parallel_pieces(int pieces, int64_t count, Fn fn) {
+  pieces = (int)std::max<int64_t>(1, std::min<int64_t>(pieces, count));
+  const int64_t per = (count + pieces - 1) / pieces;
+  if (pieces == 1) {
+    try { fn(0, (int64_t)0, count); } catch (...) { return false; }
+    return true;
+  }
+  std::vector<char> ok((size_t)pieces, 1);
+  std::vector<std::thread> th;
+  th.reserve((size_t)pieces);
+  for (int t = 0; t < pieces; ++t) {
+    const int64_t b = std::min(count, t * per), e = std::min(count, b + per);
+    try {
+      th.emplace_back([&, t, b, e]() {
+        try { fn(t, b, e); } catch (...) { ok[(size_t)t] = 0; }
+      });
+    } catch (...) {  // no thread to be had: do the piece here
+      try { fn(t, b, e); } catch (...) { ok[(size_t)t] = 0; }
+    }
+  }
+  for (auto &x : th) x.join();
+  return std::all_of(ok.begin(), ok.end(), [](char c) { return c != 0; });
+}
+
 // wall time of the phases of an operator's creation, printed under SLQ_DEBUG (scripts/time_create.py)
 struct PhaseClock {
   bool on = env_int("SLQ_DEBUG", 0) != 0;
@@ -339,87 +382,87 @@ static int check_dtype(int dtype) {
 static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm, int sub,
                                 double *avg_level) {
   perm.resize((size_t)n);
-  int64_t levels = 0, levelled = 0;  // of the committed searches since the last reset
   const int64_t chunk = (n + 7) / 8;
-  // Reverse Cuthill-McKee of the subgraph induced by `members` (all with part[v] == id), appended to `out`.
-  std::vector<int32_t> deg((size_t)n), part((size_t)n, -1), nbrs, order;
+  // The eight chunks are independent: one worker each. deg / part / seen are indexed by node and a worker touches the
+  // entries of its own chunk only (a neighbour's entry is read only after its index has been found inside the chunk).
+  std::vector<int32_t> deg((size_t)n), part((size_t)n, -1);
   std::vector<char> seen((size_t)n, 0);
-  auto rcm = [&](const std::vector<int32_t> &members, int32_t id, std::vector<int32_t> &out) {
-    for (int32_t v : members) {
-      int d = 0;
-      for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) d += (part[(size_t)colind[p]] == id && colind[p] != v);
-      deg[(size_t)v] = d;
-    }
-    order.clear();
-    // candidates in increasing degree: starting points of the components
-    std::vector<int32_t> cand(members);
-    std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
-    auto bfs = [&](int32_t start, bool commit, int32_t *last_min) {
-      // breadth-first numbering with neighbours in increasing degree (Cuthill-McKee)
-      const size_t base = order.size();
-      order.push_back(start);
-      seen[(size_t)start] = 1;
-      size_t head = base, level_begin = base;
-      while (head < order.size()) {
-        const size_t level_end = order.size();
-        level_begin = head;
-        if (commit) {
-          ++levels;
-          levelled += (int64_t)(level_end - head);
-        }
-        for (; head < level_end; ++head) {
-          const int32_t u = order[head];
-          nbrs.clear();
-          for (int32_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
-            const int32_t v = colind[p];
-            if (part[(size_t)v] == id && !seen[(size_t)v]) {
-              seen[(size_t)v] = 1;
-              nbrs.push_back(v);
-            }
-          }
-          std::sort(nbrs.begin(), nbrs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b] || (deg[(size_t)a] == deg[(size_t)b] && a < b); });
-          order.insert(order.end(), nbrs.begin(), nbrs.end());
-        }
-      }
-      // min-degree node of the last level: a pseudo-peripheral candidate
-      int32_t far = order[level_begin];
-      for (size_t q = level_begin; q < order.size(); ++q)
-        if (deg[(size_t)order[q]] < deg[(size_t)far]) far = order[q];
-      if (last_min) *last_min = far;
-      if (!commit) {
-        for (size_t q = base; q < order.size(); ++q) seen[(size_t)order[q]] = 0;
-        order.resize(base);
-      }
-    };
-    for (int32_t c : cand) {
-      if (seen[(size_t)c]) continue;
-      int32_t far = c;
-      bfs(c, false, &far);      // one pseudo-peripheral refinement
-      bfs(far, true, nullptr);
-    }
-    for (int32_t v : members) seen[(size_t)v] = 0;
-    out.insert(out.end(), order.rbegin(), order.rend());  // reversed (RCM)
-  };
-  // Second level (SLQ_RCM_SUB = K > 1): the chunk's RCM order is cut into K consecutive pieces of equal size - runs of
-  // BFS levels, i.e. slices ACROSS the chunk's longest direction - and each piece is reordered on its own. A piece is
-  // short along the old sweep direction, so its own Cuthill-McKee levels run along another one and are K times
-  // smaller: the gather halo an XCD's L2 has to hold shrinks accordingly, at the price of the edges cut between pieces.
   sub = std::max(1, sub);
-  int64_t levels_all = 0, levelled_all = 0;
-  std::vector<int32_t> members, first, piece, second;
-  for (int x = 0; x < 8; ++x) {
+  int64_t levels_x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, levelled_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto do_chunk = [&](int x) {
     const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
-    if (lo >= hi) break;
+    if (lo >= hi) return;
+    int64_t levels = 0, levelled = 0;  // of the committed searches since the last reset
+    std::vector<int32_t> nbrs, order, members, first, piece, second;
+    auto inside = [&](int32_t v, int32_t id) { return v >= lo && v < hi && part[(size_t)v] == id; };
+    // Reverse Cuthill-McKee of the subgraph induced by `members` (all with part[v] == id), appended to `out`.
+    auto rcm = [&](const std::vector<int32_t> &mem, int32_t id, std::vector<int32_t> &out) {
+      for (int32_t v : mem) {
+        int d = 0;
+        for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) d += (colind[p] != v && inside(colind[p], id));
+        deg[(size_t)v] = d;
+      }
+      order.clear();
+      // candidates in increasing degree: starting points of the components
+      std::vector<int32_t> cand(mem);
+      std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+      auto bfs = [&](int32_t start, bool commit, int32_t *last_min) {
+        // breadth-first numbering with neighbours in increasing degree (Cuthill-McKee)
+        const size_t base = order.size();
+        order.push_back(start);
+        seen[(size_t)start] = 1;
+        size_t head = base, level_begin = base;
+        while (head < order.size()) {
+          const size_t level_end = order.size();
+          level_begin = head;
+          if (commit) {
+            ++levels;
+            levelled += (int64_t)(level_end - head);
+          }
+          for (; head < level_end; ++head) {
+            const int32_t u = order[head];
+            nbrs.clear();
+            for (int32_t p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+              const int32_t v = colind[p];
+              if (inside(v, id) && !seen[(size_t)v]) {
+                seen[(size_t)v] = 1;
+                nbrs.push_back(v);
+              }
+            }
+            std::sort(nbrs.begin(), nbrs.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b] || (deg[(size_t)a] == deg[(size_t)b] && a < b); });
+            order.insert(order.end(), nbrs.begin(), nbrs.end());
+          }
+        }
+        // min-degree node of the last level: a pseudo-peripheral candidate
+        int32_t far = order[level_begin];
+        for (size_t q = level_begin; q < order.size(); ++q)
+          if (deg[(size_t)order[q]] < deg[(size_t)far]) far = order[q];
+        if (last_min) *last_min = far;
+        if (!commit) {
+          for (size_t q = base; q < order.size(); ++q) seen[(size_t)order[q]] = 0;
+          order.resize(base);
+        }
+      };
+      for (int32_t c : cand) {
+        if (seen[(size_t)c]) continue;
+        int32_t far = c;
+        bfs(c, false, &far);      // one pseudo-peripheral refinement
+        bfs(far, true, nullptr);
+      }
+      for (int32_t v : mem) seen[(size_t)v] = 0;
+      out.insert(out.end(), order.rbegin(), order.rend());  // reversed (RCM)
+    };
     members.resize((size_t)(hi - lo));
     for (int64_t i = lo; i < hi; ++i) {
       members[(size_t)(i - lo)] = (int32_t)i;
       part[(size_t)i] = x;
     }
-    first.clear();
-    levels = levelled = 0;
     rcm(members, x, first);
+    // Second level (SLQ_RCM_SUB = K > 1): the chunk's RCM order is cut into K consecutive pieces of equal size - runs of
+    // BFS levels, i.e. slices ACROSS the chunk's longest direction - and each piece is reordered on its own. A piece is
+    // short along the old sweep direction, so its own Cuthill-McKee levels run along another one and are K times
+    // smaller: the gather halo an XCD's L2 has to hold shrinks accordingly, at the price of the edges cut between pieces.
     if (sub > 1 && (int64_t)first.size() >= 64 * sub) {
-      second.clear();
       levels = levelled = 0;
       const size_t len = (first.size() + sub - 1) / sub;
       for (int k = 0; k < sub; ++k) {
@@ -431,10 +474,17 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       }
       first.swap(second);
     }
-    levels_all += levels;
-    levelled_all += levelled;
+    levels_x[x] = levels;
+    levelled_x[x] = levelled;
     for (int64_t q = 0; q < hi - lo; ++q) perm[(size_t)(lo + q)] = first[(size_t)q];
+  };
+  if (host_threads() > 1) {
+    if (!parallel_pieces(8, 8, [&](int, int64_t x0, int64_t x1) { for (int64_t x = x0; x < x1; ++x) do_chunk((int)x); })) throw std::bad_alloc();
+  } else {
+    for (int x = 0; x < 8; ++x) do_chunk(x);
   }
+  int64_t levels_all = 0, levelled_all = 0;
+  for (int x = 0; x < 8; ++x) levels_all += levels_x[x], levelled_all += levelled_x[x];
   if (avg_level) *avg_level = levels_all > 0 ? (double)levelled_all / (double)levels_all : 0.0;
 }
 
@@ -453,17 +503,21 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
   const int tmax = ringed ? kRingTileRows : std::max(1, std::min(env_int("SLQ_TILE_ROWS", kTileRows), 64));
   const int dcap = ringed ? kRingTileCols : std::max(8, std::min(env_int("SLQ_TILE_COLS", kTileCols), kTileCols));
   const int nzcap = ringed ? kRingTileNnz : std::numeric_limits<int>::max();  // the ring kernel's tile record is bounded
+  // The chunks are independent (a cluster never leaves its chunk): one worker each, with its own order, its own tile
+  // boundaries (counted from the chunk's first row) and its own stamp array; `assigned` is shared, but a worker reads and
+  // writes the entries of its own chunk's rows only.
   std::vector<char> assigned((size_t)n, 0);
-  std::vector<int32_t> stamp((size_t)n, -1);
-  struct Cand { int32_t node, cnt, disc; };
-  std::vector<Cand> cand;
-  order_out.clear();
-  order_out.reserve((size_t)n);
-  tile_row.assign(1, 0);
-  int32_t cid = 0;
-  for (int x = 0; x < 8; ++x) {
-    xcd_tile[x] = (int32_t)tile_row.size() - 1;
+  std::vector<int32_t> order_x[8], rows_x[8];  // per chunk: the new order, and the row count of every cluster
+  char failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto do_chunk = [&](int x) {
     const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    if (lo >= hi) return;
+    std::vector<int32_t> stamp((size_t)n, -1);
+    struct Cand { int32_t node, cnt, disc; };
+    std::vector<Cand> cand;
+    std::vector<int32_t> &order = order_x[x];
+    order.reserve((size_t)(hi - lo));
+    int32_t cid = 0;
     auto in_chunk = [&](int32_t v) {
       const int64_t b = inv_in ? inv_in[v] : v;
       return b >= lo && b < hi;
@@ -473,7 +527,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
       if (assigned[(size_t)seed]) continue;
       int D = 0, ndisc = 0, nz = 0;
       cand.clear();
-      const size_t first_member = order_out.size();
+      const size_t first_member = order.size();
       auto new_cols = [&](int32_t v) {
         int c = stamp[(size_t)v] != cid;
         for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) c += (stamp[(size_t)colind[p]] != cid && colind[p] != v);
@@ -481,22 +535,22 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
       };
       auto add = [&](int32_t v) {
         assigned[(size_t)v] = 1;
-        order_out.push_back(v);
+        order.push_back(v);
         nz += rowptr[v + 1] - rowptr[v];
         if (stamp[(size_t)v] != cid) { stamp[(size_t)v] = cid; ++D; }
         for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) {
           const int32_t c = colind[p];
           if (stamp[(size_t)c] != cid) { stamp[(size_t)c] = cid; ++D; }
-          if (c != v && !assigned[(size_t)c] && in_chunk(c)) {
+          if (c != v && in_chunk(c) && !assigned[(size_t)c]) {
             bool found = false;
             for (auto &k : cand) if (k.node == c) { ++k.cnt; found = true; break; }
             if (!found) cand.push_back(Cand{c, 1, ndisc++});
           }
         }
       };
-      if (new_cols(seed) > dcap || rowptr[seed + 1] - rowptr[seed] > nzcap) return false;
+      if (new_cols(seed) > dcap || rowptr[seed + 1] - rowptr[seed] > nzcap) { failed[x] = 1; return; }
       add(seed);
-      while ((int)(order_out.size() - first_member) < tmax && !cand.empty()) {
+      while ((int)(order.size() - first_member) < tmax && !cand.empty()) {
         size_t best = 0;
         for (size_t q = 1; q < cand.size(); ++q)
           if (cand[q].cnt > cand[best].cnt || (cand[q].cnt == cand[best].cnt && cand[q].disc < cand[best].disc)) best = q;
@@ -507,9 +561,23 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
         if (D + new_cols(v) > dcap || nz + rowptr[v + 1] - rowptr[v] > nzcap) continue;  // would not fit: leave it for a later cluster
         add(v);
       }
-      tile_row.push_back((int32_t)order_out.size());
+      rows_x[x].push_back((int32_t)(order.size() - first_member));
       ++cid;
     }
+  };
+  if (host_threads() > 1) {
+    if (!parallel_pieces(8, 8, [&](int, int64_t x0, int64_t x1) { for (int64_t x = x0; x < x1; ++x) do_chunk((int)x); })) return false;
+  } else {
+    for (int x = 0; x < 8; ++x) do_chunk(x);
+  }
+  order_out.clear();
+  order_out.reserve((size_t)n);
+  tile_row.assign(1, 0);
+  for (int x = 0; x < 8; ++x) {
+    if (failed[x]) return false;
+    xcd_tile[x] = (int32_t)tile_row.size() - 1;
+    order_out.insert(order_out.end(), order_x[x].begin(), order_x[x].end());
+    for (int32_t r : rows_x[x]) tile_row.push_back(tile_row.back() + r);
   }
   xcd_tile[8] = (int32_t)tile_row.size() - 1;
   for (int x = 7; x >= 0; --x) xcd_tile[x] = std::min(xcd_tile[x], xcd_tile[x + 1]);
@@ -581,41 +649,52 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
   tile_cols.clear();
   lcol.assign((size_t)rowptr[n] + kCsrPad, 0);
   self_idx.assign((size_t)n, 0);
-  std::vector<int32_t> u, pos, ordered;
   const int line_order = env_int("SLQ_RING_ORDER", 0);
-  int mx = 0;
-  for (size_t t = 0; t < ntiles; ++t) {
-    const int64_t r0 = tile_row[t], r1 = tile_row[t + 1];
-    u.clear();
-    for (int64_t r = r0; r < r1; ++r) {
-      u.push_back((int32_t)r);
-      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) u.push_back(colind[p]);
+  const int pieces = host_threads();
+  std::vector<std::vector<int32_t>> local((size_t)pieces);  // every piece's lists, in tile order
+  std::vector<int> mx_piece((size_t)pieces, 0);
+  const bool ok = parallel_pieces(pieces, (int64_t)ntiles, [&](int piece, int64_t t0, int64_t t1) {
+    std::vector<int32_t> u, pos, ordered;
+    std::vector<int32_t> &mine = local[(size_t)piece];
+    int mx = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t r0 = tile_row[(size_t)t], r1 = tile_row[(size_t)t + 1];
+      u.clear();
+      for (int64_t r = r0; r < r1; ++r) {
+        u.push_back((int32_t)r);
+        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) u.push_back(colind[p]);
+      }
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      mx = std::max(mx, (int)u.size());
+      // position of every distinct index in the tile's list = the order its panel rows are landed in. Ascending by default;
+      // line_order 1: the tile's own rows first, then the rows below them, then the rows above (experiments, SLQ_RING_ORDER)
+      pos.resize(u.size());
+      if (line_order == 0) {
+        for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)q;
+      } else {
+        const size_t lo = (size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r0) - u.begin());
+        const size_t own = (size_t)(r1 - r0);
+        for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)(q < lo ? own + q : (q < lo + own ? q - lo : q));
+      }
+      ordered.resize(u.size());
+      for (size_t q = 0; q < u.size(); ++q) ordered[(size_t)pos[q]] = u[q];
+      for (int64_t r = r0; r < r1; ++r) {
+        self_idx[(size_t)r] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin())];
+        for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
+          lcol[(size_t)p] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin())];
+      }
+      mine.insert(mine.end(), ordered.begin(), ordered.end());
+      tile_ptr[(size_t)t + 1] = (int32_t)ordered.size();  // (the list's length for now; offsets below)
     }
-    std::sort(u.begin(), u.end());
-    u.erase(std::unique(u.begin(), u.end()), u.end());
-    mx = std::max(mx, (int)u.size());
-    // position of every distinct index in the tile's list = the order its panel rows are landed in. Ascending by default;
-    // line_order 1: the tile's own rows first, then the rows below them, then the rows above (experiments, SLQ_RING_ORDER)
-    pos.resize(u.size());
-    if (line_order == 0) {
-      for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)q;
-    } else {
-      const size_t lo = (size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r0) - u.begin());
-      const size_t own = (size_t)(r1 - r0);
-      for (size_t q = 0; q < u.size(); ++q) pos[q] = (int32_t)(q < lo ? own + q : (q < lo + own ? q - lo : q));
-    }
-    ordered.resize(u.size());
-    for (size_t q = 0; q < u.size(); ++q) ordered[(size_t)pos[q]] = u[q];
-    for (int64_t r = r0; r < r1; ++r) {
-      self_idx[(size_t)r] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), (int32_t)r) - u.begin())];
-      for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p)
-        lcol[(size_t)p] = pos[(size_t)(std::lower_bound(u.begin(), u.end(), colind[p]) - u.begin())];
-    }
-    tile_cols.insert(tile_cols.end(), ordered.begin(), ordered.end());
-    tile_ptr[t + 1] = (int32_t)tile_cols.size();
-  }
+    mx_piece[(size_t)piece] = mx;
+  });
+  if (!ok) throw std::bad_alloc();
+  for (size_t t = 0; t < ntiles; ++t) tile_ptr[t + 1] += tile_ptr[t];
+  tile_cols.reserve((size_t)tile_ptr[ntiles] + kCsrPad);
+  for (auto &v : local) tile_cols.insert(tile_cols.end(), v.begin(), v.end());
   tile_cols.insert(tile_cols.end(), kCsrPad, 0);
-  *max_cols = mx;
+  *max_cols = *std::max_element(mx_piece.begin(), mx_piece.end());
 }
 
 // What the ring-fed passes read (SLQ_TILES=2; layouts in slq_kernels.hpp / slq_ring.hpp): per tile a descriptor of R blocks
@@ -631,69 +710,83 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
   const size_t dw = (size_t)64 * R, head_bytes = (size_t)kRecHeadBytes * R;
   const int valoff_w = 16 * R - 1, self_w = 16 * R;
   desc.assign(ntiles * dw, 0);
-  rec.clear();
+  // where every record starts (its size follows from the tile's nonzero count alone), then the tiles in parallel
+  std::vector<size_t> off(ntiles + 1, 0);
   for (size_t t = 0; t < ntiles; ++t) {
-    const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
-    const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
-    const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = head_bytes + nzp * 4, bytes = (valoff + nzp * sizeof(F) + 15) / 16 * 16;
-    const size_t off = rec.size();
-    rec.resize(off + bytes, 0);
-    int32_t *head = (int32_t *)(rec.data() + off);
-    for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
-    head[valoff_w] = (int32_t)valoff;
-    for (int32_t i = 0; i < rows; ++i) head[self_w + i] = self_idx[(size_t)(r0 + i)];
-    memcpy(rec.data() + off + head_bytes, lcol.data() + p0, (size_t)nz * 4);
-    memcpy(rec.data() + off + valoff, vals + p0, (size_t)nz * sizeof(F));
-    int32_t *d = desc.data() + t * dw;
-    d[kDescCols] = D;
-    d[kDescRecOff] = (int32_t)(off / 16);
-    d[kDescRecChunks] = (int32_t)((bytes + 1023) / 1024);
-    d[kDescRow0] = r0;
-    d[kDescRows] = rows;
-    const int32_t nd = (D + R - 1) / R;
-    for (int32_t c = 0; c < nd * R; ++c) d[(size_t)(c % R) * 64 + kDescList + c / R] = tile_cols[(size_t)tile_ptr[t] + std::min(c, D - 1)];
+    const int32_t r0 = tile_row[t], nz = rowptr[tile_row[t + 1]] - rowptr[r0];
+    const size_t nzp = ((size_t)nz + 3) / 4 * 4;
+    off[t + 1] = off[t] + (head_bytes + nzp * 4 + nzp * sizeof(F) + 15) / 16 * 16;
   }
-  rec.resize(rec.size() + (size_t)kRingMetaBytes * R, 0);
+  rec.assign(off[ntiles] + (size_t)kRingMetaBytes * R, 0);
+  const bool ok = parallel_pieces(host_threads(), (int64_t)ntiles, [&](int, int64_t t0, int64_t t1) {
+    for (int64_t tt = t0; tt < t1; ++tt) {
+      const size_t t = (size_t)tt;
+      const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
+      const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
+      const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = head_bytes + nzp * 4, bytes = off[t + 1] - off[t];
+      int32_t *head = (int32_t *)(rec.data() + off[t]);
+      for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
+      head[valoff_w] = (int32_t)valoff;
+      for (int32_t i = 0; i < rows; ++i) head[self_w + i] = self_idx[(size_t)(r0 + i)];
+      memcpy(rec.data() + off[t] + head_bytes, lcol.data() + p0, (size_t)nz * 4);
+      memcpy(rec.data() + off[t] + valoff, vals + p0, (size_t)nz * sizeof(F));
+      int32_t *d = desc.data() + t * dw;
+      d[kDescCols] = D;
+      d[kDescRecOff] = (int32_t)(off[t] / 16);
+      d[kDescRecChunks] = (int32_t)((bytes + 1023) / 1024);
+      d[kDescRow0] = r0;
+      d[kDescRows] = rows;
+      const int32_t nd = (D + R - 1) / R;
+      for (int32_t c = 0; c < nd * R; ++c) d[(size_t)(c % R) * 64 + kDescList + c / R] = tile_cols[(size_t)tile_ptr[t] + std::min(c, D - 1)];
+    }
+  });
+  if (!ok) throw std::bad_alloc();
 }
 
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
-// upper entries doubled and return true. One pass with a per-row cursor: rows are visited in ascending i,
-// so the lower entries (j, i) of row j are met in the order they are stored.
+// upper entries doubled and return true. Row ranges in parallel: every off-diagonal entry (i, j) looks its mirror (j, i)
+// up by bisection in row j (rows are sorted - checked on the way) and compares the values; the upper entries are then
+// counted per row, placed by a prefix sum and written, again by row ranges.
 template <typename F>
 static bool build_symmetric_upper(int64_t n, const int32_t *rowptr, const int32_t *colind, const F *vals,
                                   std::vector<int32_t> &urp, std::vector<int32_t> &uci, std::vector<char> &uva) {
-  std::vector<int32_t> cur(rowptr, rowptr + n);
   urp.assign((size_t)n + 1, 0);
-  size_t nu = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
-      const int32_t j = colind[q];
-      if (q > rowptr[i] && colind[q - 1] >= j) return false;  // unsorted or duplicate
-      if (j >= i) ++nu;
-      if (j > i) {
-        const int32_t c = cur[(size_t)j];
-        if (c >= rowptr[j + 1] || colind[c] != (int32_t)i || !(vals[c] == vals[q])) return false;
-        cur[(size_t)j] = c + 1;
-      }
-    }
-  }
-  for (int64_t j = 0; j < n; ++j)   // every lower entry must have been claimed by its mirror
-    if (cur[(size_t)j] < rowptr[j + 1] && colind[cur[(size_t)j]] < j) return false;
+  const int pieces = host_threads();
+  std::vector<char> bad((size_t)pieces, 0);
+  if (!parallel_pieces(pieces, n, [&](int piece, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1 && !bad[(size_t)piece]; ++i) {
+          int32_t up = 0;
+          for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+            const int32_t j = colind[q];
+            if (q > rowptr[i] && colind[q - 1] >= j) { bad[(size_t)piece] = 1; break; }  // unsorted or duplicate
+            up += j >= i;
+            if (j == i) continue;
+            const int32_t *lo = colind + rowptr[j], *hi = colind + rowptr[j + 1];
+            const int32_t *m = std::lower_bound(lo, hi, (int32_t)i);
+            if (m == hi || *m != (int32_t)i || !(vals[m - colind] == vals[q])) { bad[(size_t)piece] = 1; break; }
+          }
+          urp[(size_t)i + 1] = up;
+        }
+      }))
+    return false;
+  if (std::any_of(bad.begin(), bad.end(), [](char c) { return c != 0; })) return false;
+  for (int64_t i = 0; i < n; ++i) urp[(size_t)i + 1] += urp[(size_t)i];
+  const size_t nu = (size_t)urp[(size_t)n];
   uci.resize(nu);
   uva.resize(nu * sizeof(F));
   F *uv = (F *)uva.data();
-  size_t w = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
-      const int32_t j = colind[q];
-      if (j < i) continue;
-      uci[w] = j;
-      uv[w] = j == i ? vals[q] : (F)2 * vals[q];
-      ++w;
+  return parallel_pieces(pieces, n, [&](int, int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; ++i) {
+      size_t w = (size_t)urp[(size_t)i];
+      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+        const int32_t j = colind[q];
+        if (j < i) continue;
+        uci[w] = j;
+        uv[w] = j == i ? vals[q] : (F)2 * vals[q];
+        ++w;
+      }
     }
-    urp[(size_t)i + 1] = (int32_t)w;
-  }
-  return true;
+  });
 }
 
 // plain != 0: rows stay in the caller's order and no derived copy (upper triangle, tiles) is built - for operators whose
@@ -707,7 +800,19 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
   return csr_create_impl(ctx, dtype, n, nnz, rowptr, colind, vals, out, 0);
 }
 
+static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
+                           const void *vals, slq_operator **out, int plain);
 static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
+                           const void *vals, slq_operator **out, int plain) {
+  try {  // (host-side allocations of the analysis: no C++ exception crosses the C boundary)
+    return csr_create_body(ctx, dtype, n, nnz, rowptr, colind, vals, out, plain);
+  } catch (const std::bad_alloc &) {
+    if (out) *out = nullptr;
+    return fail(SLQ_ENOMEM, "host allocation failed while analysing the operator");
+  }
+}
+
+static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
                            const void *vals, slq_operator **out, int plain) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
   *out = nullptr;
@@ -746,19 +851,29 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   // chunks are served by another XCD's L2 whatever the order inside the chunks)
   const int64_t rchunk = (n + 7) / 8;
   auto mean_dist = [&](const std::vector<int32_t> *inv) {
-    double acc = 0.0;
-    int64_t cnt = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      const int64_t ii = inv ? (*inv)[(size_t)i] : i;
-      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
-        if (colind[q] / rchunk != i / rchunk) continue;
-        const int64_t jj = inv ? (*inv)[(size_t)colind[q]] : colind[q];
-        const double dd = (double)(ii > jj ? ii - jj : jj - ii);
-        acc += dd * dd;
-        ++cnt;
+    const int pieces = 8;  // (a fixed partition: the sum does not depend on how many threads ran it)
+    std::vector<double> acc((size_t)pieces, 0.0);
+    std::vector<int64_t> cnt((size_t)pieces, 0);
+    parallel_pieces(pieces, n, [&](int piece, int64_t i0, int64_t i1) {
+      double a = 0.0;
+      int64_t c = 0;
+      for (int64_t i = i0; i < i1; ++i) {
+        const int64_t ii = inv ? (*inv)[(size_t)i] : i;
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+          if (colind[q] / rchunk != i / rchunk) continue;
+          const int64_t jj = inv ? (*inv)[(size_t)colind[q]] : colind[q];
+          const double dd = (double)(ii > jj ? ii - jj : jj - ii);
+          a += dd * dd;
+          ++c;
+        }
       }
-    }
-    return std::sqrt(acc / (double)std::max<int64_t>(cnt, 1));
+      acc[(size_t)piece] = a;
+      cnt[(size_t)piece] = c;
+    });
+    double a = 0.0;
+    int64_t c = 0;
+    for (int t = 0; t < pieces; ++t) a += acc[(size_t)t], c += cnt[(size_t)t];  // (piece order: the same value whatever the timing)
+    return std::sqrt(a / (double)std::max<int64_t>(c, 1));
   };
   // Workgroup tiles (SLQ_TILES, tiles_mode()): the rows are regrouped into compact clusters = the tiles of k_csr_tile_pass /
   // k_csr_ring_pass, on top of a base order. Kept only if the tiles actually share rows: at most kTileMaxColsPerRow distinct
@@ -791,16 +906,28 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       for (int64_t i = 0; i < n; ++i) inv0[(size_t)(*base)[(size_t)i]] = (int32_t)i;
     }
     if (!build_clusters(n, rowptr, colind, base ? base->data() : nullptr, base ? inv0.data() : nullptr, order, tile_row, xcd_tile)) return false;
-    // distinct indices per tile row, on the caller's numbering (the exact lists are built below)
-    int64_t dsum = 0;
-    std::vector<int32_t> stamp((size_t)n, -1);
-    for (size_t t = 0; t + 1 < tile_row.size(); ++t)
-      for (int32_t q = tile_row[t]; q < tile_row[t + 1]; ++q) {
-        const int32_t v = order[(size_t)q];
-        if (stamp[(size_t)v] != (int32_t)t) { stamp[(size_t)v] = (int32_t)t; ++dsum; }
-        for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp)
-          if (stamp[(size_t)colind[pp]] != (int32_t)t) { stamp[(size_t)colind[pp]] = (int32_t)t; ++dsum; }
+    clk.lap("  clusters");
+    // distinct indices per tile row, on the caller's numbering (the exact lists are built below); tile ranges in parallel
+    const int pieces = host_threads();
+    std::vector<int64_t> dpart((size_t)pieces, 0);
+    parallel_pieces(pieces, (int64_t)tile_row.size() - 1, [&](int piece, int64_t t0, int64_t t1) {
+      std::vector<int32_t> u;
+      int64_t d = 0;
+      for (int64_t t = t0; t < t1; ++t) {
+        u.clear();
+        for (int32_t q = tile_row[(size_t)t]; q < tile_row[(size_t)t + 1]; ++q) {
+          const int32_t v = order[(size_t)q];
+          u.push_back(v);
+          for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp) u.push_back(colind[pp]);
+        }
+        std::sort(u.begin(), u.end());
+        d += (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
       }
+      dpart[(size_t)piece] = d;
+    });
+    int64_t dsum = 0;
+    for (int64_t d : dpart) dsum += d;
+    clk.lap("  lines per row");
     const double per_row = (double)dsum / (double)n;
     if (env_int("SLQ_DEBUG", 0) != 0)
       fprintf(stderr, "[slq] tiles: %zu clusters, %.2f rows each, %.2f distinct panel rows per row (limit %.1f)\n", tile_row.size() - 1,
@@ -833,6 +960,7 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       double w = 0.0;
       for (int k = 1; k <= 64; k *= 4) {
         xcd_rcm_permutation(n, rowptr, colind, rcm_perm, k, &w);
+        clk.lap("  Cuthill-McKee in the chunks");
         if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: %d piece(s) per chunk: level sets of %.0f rows on average\n", k, w);
         if (w <= kTileLevelRows) break;
       }
@@ -890,20 +1018,26 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     ci2.resize((size_t)nnz);
     va2.resize((size_t)nnz * es);
     rp2[0] = 0;
-    std::vector<std::pair<int32_t, int32_t>> rowbuf;
     for (int64_t i = 0; i < n; ++i) {
       const int32_t o = perm[(size_t)i];
-      rowbuf.clear();
-      for (int32_t q = rowptr[o]; q < rowptr[o + 1]; ++q) rowbuf.emplace_back(inv[(size_t)colind[q]], q);
-      std::sort(rowbuf.begin(), rowbuf.end());
-      int32_t w = rp2[(size_t)i];
-      for (auto &e2 : rowbuf) {
-        ci2[(size_t)w] = e2.first;
-        memcpy(va2.data() + (size_t)w * es, (const char *)vals + (size_t)e2.second * es, es);
-        ++w;
-      }
-      rp2[(size_t)i + 1] = w;
+      rp2[(size_t)i + 1] = rp2[(size_t)i] + (rowptr[o + 1] - rowptr[o]);
     }
+    const bool pok = parallel_pieces(host_threads(), n, [&](int, int64_t i0, int64_t i1) {
+      std::vector<std::pair<int32_t, int32_t>> rowbuf;
+      for (int64_t i = i0; i < i1; ++i) {
+        const int32_t o = perm[(size_t)i];
+        rowbuf.clear();
+        for (int32_t q = rowptr[o]; q < rowptr[o + 1]; ++q) rowbuf.emplace_back(inv[(size_t)colind[q]], q);
+        std::sort(rowbuf.begin(), rowbuf.end());
+        int32_t w = rp2[(size_t)i];
+        for (auto &e2 : rowbuf) {
+          ci2[(size_t)w] = e2.first;
+          memcpy(va2.data() + (size_t)w * es, (const char *)vals + (size_t)e2.second * es, es);
+          ++w;
+        }
+      }
+    });
+    if (!pok) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
     rowptr = rp2.data();
     colind = ci2.data();
     vals = va2.data();
@@ -918,9 +1052,15 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   {
     // gathers per row that reach further than any cache-resident halo (|i - j| > 4096 rows in the stored
     // order): what decides between the recompute passes and the store-and-revisit sweeps (enqueue_run)
+    std::vector<int64_t> farp((size_t)host_threads(), 0);
+    parallel_pieces((int)farp.size(), n, [&](int piece, int64_t i0, int64_t i1) {
+      int64_t f = 0;
+      for (int64_t i = i0; i < i1; ++i)
+        for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) f += std::llabs((long long)colind[q] - (long long)i) > 4096;
+      farp[(size_t)piece] = f;
+    });
     int64_t far = 0;
-    for (int64_t i = 0; i < n; ++i)
-      for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) far += std::llabs((long long)colind[q] - (long long)i) > 4096;
+    for (int64_t f : farp) far += f;
     op->far_per_row = (double)far / (double)n;
   }
   if (env_int("SLQ_DEBUG", 0) != 0)
@@ -2049,21 +2189,62 @@ static int init_from_probes(slq_plan *p, int sphere) {
   return SLQ_OK;
 }
 
+// two pinned buffers of `bytes` each on the context (kept for its lifetime); false when the host cannot pin that much
+static bool ensure_pinned(slq_context *ctx, size_t bytes) {
+  if (ctx->pin_bytes >= bytes && ctx->pin[0] && ctx->pin[1]) return true;
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->pin[b]) hipHostFree(ctx->pin[b]);
+    ctx->pin[b] = nullptr;
+    ctx->pin_busy[b] = false;
+  }
+  ctx->pin_bytes = 0;
+  for (int b = 0; b < 2; ++b) {
+    if (hipHostMalloc(&ctx->pin[b], bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!ctx->pin_ev[b] && hipEventCreateWithFlags(&ctx->pin_ev[b], hipEventDisableTiming) != hipSuccess) return false;
+  }
+  ctx->pin_bytes = bytes;
+  return true;
+}
+
 extern "C" int slq_plan_set_probes(slq_plan *p, const void *X, int64_t ldx) {
   if (!p || !X) return fail(SLQ_EINVAL, "plan/X is NULL");
   if (ldx < p->n) return fail(SLQ_EINVAL, "ldx (%lld) < n (%d)", (long long)ldx, p->n);
   HIP_TRY(hipSetDevice(p->ctx->device));
   hipStream_t st = p->ctx->stream;
-  const int cc = stage_chunk_cols(p);
+  slq_context *ctx = p->ctx;
+  // The caller's array is pageable memory: copied straight from there, the runtime bounces it through its own small
+  // pinned buffers at ~10 GB/s (configs[1]: 2 GB of probes, 0.2 s). Here the columns are copied by a few host threads
+  // into one of two pinned buffers (32 MiB chunks) and sent from there; the copy of chunk i + 1 overlaps the transfer
+  // and the transposition kernel of chunk i. SLQ_PINNED_UPLOAD=0 keeps the direct copy.
+  const size_t col_bytes = (size_t)p->n * p->esz;
+  const bool pinned = env_int("SLQ_PINNED_UPLOAD", 1) != 0 && (size_t)p->nprobes * col_bytes >= ((size_t)4 << 20);
+  int cc = stage_chunk_cols(p);
+  if (pinned) cc = (int)std::max<size_t>(1, std::min<size_t>((size_t)cc, ((size_t)32 << 20) / col_bytes));
+  const bool use_pin = pinned && ensure_pinned(ctx, (size_t)cc * col_bytes);
+  if (!use_pin) cc = stage_chunk_cols(p);
   SLQ_TRY(ensure_stage(p, cc));
   // padding columns must be zero
   if (p->nprobes < p->bpad)
     HIP_TRY(hipMemsetAsync(slot_ptr(p, 0), 0, (size_t)p->slot_stride * p->esz, st));
+  int buf = 0;
   for (int c0 = 0; c0 < p->nprobes; c0 += cc) {
     const int nc = std::min(cc, p->nprobes - c0);
     const char *src = (const char *)X + (size_t)c0 * (size_t)ldx * p->esz;
-    HIP_TRY(hipMemcpy2DAsync(p->stage, (size_t)p->n * p->esz, src, (size_t)ldx * p->esz,
-                             (size_t)p->n * p->esz, (size_t)nc, hipMemcpyHostToDevice, st));
+    if (use_pin) {
+      if (ctx->pin_busy[buf]) HIP_TRY(hipEventSynchronize(ctx->pin_ev[buf]));  // its previous transfer has left the buffer
+      char *dst = (char *)ctx->pin[buf];
+      // rows of the chunk cut into pieces: every thread copies its row range of every column (contiguous runs)
+      parallel_pieces(host_threads(), p->n, [&](int, int64_t r0, int64_t r1) {
+        for (int c = 0; c < nc; ++c)
+          memcpy(dst + (size_t)c * col_bytes + (size_t)r0 * p->esz, src + (size_t)c * (size_t)ldx * p->esz + (size_t)r0 * p->esz, (size_t)(r1 - r0) * p->esz);
+      });
+      HIP_TRY(hipMemcpyAsync(p->stage, dst, (size_t)nc * col_bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipEventRecord(ctx->pin_ev[buf], st));
+      ctx->pin_busy[buf] = true;
+      buf ^= 1;
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(p->stage, col_bytes, src, (size_t)ldx * p->esz, col_bytes, (size_t)nc, hipMemcpyHostToDevice, st));
+    }
     dim3 g((p->n + 63) / 64, (nc + 63) / 64);
     PROFILED(p, SLQ_K_PROBES, {
       if (p->dtype == SLQ_F64)
@@ -2071,8 +2252,9 @@ extern "C" int slq_plan_set_probes(slq_plan *p, const void *X, int64_t ldx) {
       else
         hipLaunchKernelGGL(k_cols_to_panel<float>, g, dim3(256), 0, st, p->n, (const float *)p->stage, c0, nc, (float *)slot_ptr(p, 0), p->PW, p->op->perm_d);
     });
-    HIP_TRY(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
+    if (!use_pin) HIP_TRY(hipStreamSynchronize(st));  // the caller's memory and the staging buffer are reused by the next chunk
   }
+  // (pinned path: everything of X has been read when the loop ends; the device staging buffer is reused in stream order)
   p->pdf_sphere = 0;
   return init_from_probes(p, 0);
 }
