@@ -234,10 +234,10 @@ static int tiles_mode() { return env_int("SLQ_TILES", kTilesDefault); }
 // Host-side work of an operator's creation (row orders, clusters, tile lists, streams) is cut into independent pieces -
 // XCD chunks, tile ranges, row ranges - and run on a few threads: fn(piece, begin, end) over [0, count). Results never depend
 // on the number of threads (every piece writes its own slots or its own buffer, joined in piece order). SLQ_HOST_THREADS
-// overrides the default of min(8, hardware threads). Exceptions do not leave a worker: the first failure is reported.
+// overrides the default of min(16, hardware threads). Exceptions do not leave a worker: the first failure is reported.
 static int host_threads() {
   const int hw = (int)std::thread::hardware_concurrency();
-  return std::max(1, std::min(64, env_int("SLQ_HOST_THREADS", std::max(1, std::min(8, hw)))));
+  return std::max(1, std::min(64, env_int("SLQ_HOST_THREADS", std::max(1, std::min(16, hw)))));
 }
 template <typename Fn> static bool parallel_pieces(int pieces, int64_t count, Fn fn) {
   pieces = (int)std::max<int64_t>(1, std::min<int64_t>(pieces, count));
@@ -823,13 +823,21 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (!rowptr || (nnz > 0 && (!colind || !vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
   if (rowptr[0] != 0 || rowptr[n] != nnz)
     return fail(SLQ_EINVAL, "rowptr[0] must be 0 and rowptr[n] must equal nnz");
+  PhaseClock clk;
   for (int64_t i = 0; i < n; ++i)
     if (rowptr[i + 1] < rowptr[i]) return fail(SLQ_EINVAL, "rowptr is not non-decreasing at %lld", (long long)i);
-  for (int64_t p = 0; p < nnz; ++p)
-    if (colind[p] < 0 || colind[p] >= n)
-      return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[p], (long long)p);
+  {
+    // every column index inside [0, n): ranges of the array in parallel, the first offender (lowest position) reported
+    const int pieces = host_threads();
+    std::vector<int64_t> bad((size_t)pieces, -1);
+    parallel_pieces(pieces, nnz, [&](int piece, int64_t p0, int64_t p1) {
+      for (int64_t p = p0; p < p1; ++p)
+        if (colind[p] < 0 || colind[p] >= n) { bad[(size_t)piece] = p; break; }
+    });
+    for (int64_t b : bad)
+      if (b >= 0) return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[b], (long long)b);
+  }
   HIP_TRY(hipSetDevice(ctx->device));
-  PhaseClock clk;
   clk.lap("validation");
   if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
   slq_operator *op = new (std::nothrow) slq_operator();
@@ -1117,16 +1125,18 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     int mx = 0;
     build_tile_meta(n, rowptr, colind, tile_row, tp, tc, lc, si, &mx);
     int32_t *d_tr = nullptr, *d_tp = nullptr, *d_tc = nullptr, *d_lc = nullptr, *d_si = nullptr;
+    // (the per-nonzero lists are read by k_csr_tile_pass only: ring-sized tiles carry them inside their records instead)
+    const bool lists_on_device = tiles_mode() != 2;
     hipError_t te = hipMalloc((void **)&d_tr, tile_row.size() * 4);
     if (te == hipSuccess) te = hipMalloc((void **)&d_tp, tp.size() * 4);
-    if (te == hipSuccess) te = hipMalloc((void **)&d_tc, tc.size() * 4);
-    if (te == hipSuccess) te = hipMalloc((void **)&d_lc, lc.size() * 4);
-    if (te == hipSuccess) te = hipMalloc((void **)&d_si, si.size() * 4);
+    if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_tc, tc.size() * 4);
+    if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_lc, lc.size() * 4);
+    if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_si, si.size() * 4);
     if (te == hipSuccess) te = hipMemcpyAsync(d_tr, tile_row.data(), tile_row.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     if (te == hipSuccess) te = hipMemcpyAsync(d_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess) te = hipMemcpyAsync(d_lc, lc.data(), lc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess) te = hipMemcpyAsync(d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_lc, lc.data(), lc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     if (te == hipSuccess) te = hipStreamSynchronize(ctx->stream);
     op->tiles.tile_row = d_tr;
     op->tiles.tile_ptr = d_tp;
@@ -2493,6 +2503,10 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
                                                                                xt | ((PASS == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0), p->ring_fail_d);
         return;
       }
+    }
+    if (op->tiles_ringed) {  // never reached (enqueue_run sends ring-sized tiles to the ring-fed kernels or the generic passes)
+      fprintf(stderr, "[slq] internal: barrier-phased tile pass asked for on ring-sized tiles (pass %d, %d ring columns)\n", PASS, RC);
+      return;
     }
     if constexpr (PASS != PASS_SPMM)
     k_csr_tile_pass<F, PASS, LP, RC><<<grid, dim3(kBlock), lds, st>>>(p->n, op->rowptr, (const F *)op->vals, op->tiles.tile_row, op->tiles.tile_ptr,

@@ -1,8 +1,9 @@
 """Randomised parity sweep on the GPU box: random SPD graphs / grids, every panel geometry, orth 0..deg,
 both dtypes, against the CPU oracle on identical probes. Prints one line per failure and a summary.
 usage: python scripts/fuzz_parity.py [seconds] [seed] [tiles]
-`tiles`: operators big enough for workgroup tiles (n 4,100-45,000, SLQ_TILES=2 forced), wide panels only - the ring-fed
-tile kernels with ragged tile counts, short last tiles, empty and long rows."""
+`tiles`: operators big enough for workgroup tiles (n 4,100-45,000, SLQ_TILES=2 forced), panels of 16, 32 and 64 lanes per
+row (17-300 probes: k_ring_pass on merged tiles and k_csr_ring_pass), orth up to k (the 8-wave form for 4..8 ring columns) -
+the ring-fed tile kernels with ragged tile counts, short last (merged) tiles, empty and long rows."""
 import os, sys, time
 from pathlib import Path
 import numpy as np, scipy.sparse as sp
@@ -59,7 +60,7 @@ while time.time() - t0 < budget:
 	dtype = np.float64 if rng.random() < 0.7 else np.float32
 	P = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 257]))
 	if TILES:
-		P = int(rng.choice([128, 129, 200, 257])) if dtype == np.float64 else int(rng.choice([256, 257, 300]))
+		P = int(rng.choice([17, 20, 32, 33, 40, 64, 65, 128, 129, 200, 257])) if dtype == np.float64 else int(rng.choice([33, 40, 64, 65, 100, 128, 129, 256, 257, 300]))
 	deg = int(rng.integers(1, min(n, 20 if TILES else 40) + 1))
 	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, deg]))
 	fun, kw = [("log", {}), ("exp", {"t": -0.1}), ("identity", {}), ("sqrt", {}), ("inv", {})][int(rng.integers(0, 5))]
