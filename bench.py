@@ -89,7 +89,16 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 	for j in range(deg):
 		r = 0 if orth == 0 else min(j + 1, orth)
 		rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
-		if sequence == "fused" and r <= FUSED_MAX_R:
+		if sequence == "fused_gram" and 1 <= r <= FUSED_MAX_R:
+			## alpha-only pass (q_c alone: the -beta q_c.q_p part and every projection come from Gram rows the update passes take) and
+			## the update pass; steps with r = 0 never occur in this sequence (orth >= 1), deeper ones fall through to the sweeps
+			nz = (nnz + n) // 2 if upper_alpha else nnz
+			out["spmm_3term"] += npan * ((s + 4) * nz + 4 * (n + 1)) + vec
+			launches["spmm_3term"] += 1
+			out["reorth_update"] += csr + (rd + 1) * vec
+			launches["reorth_update"] += 1
+			continue
+		if sequence in ("fused", "fused_gram") and r <= FUSED_MAX_R:
 			if r == 0:
 				# alpha pass (orth = 0 only; with r >= 1 alpha comes out of the dots pass): q_c only (q_c.q_p comes
 				# from the previous update pass's cross term), over the upper triangle of an exactly symmetric CSR
@@ -230,7 +239,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
 	info = plan.describe()  # panel geometry and launch sequence the library chose
-	pw, fused = info["panel_width"], info["sequence"] != "sweeps"
+	pw, fused = info["panel_width"], not info["sequence"].startswith("sweeps")
 	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]))
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)

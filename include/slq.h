@@ -161,7 +161,8 @@ typedef struct {
   int ring_slots;    /* S                                                                               */
   int sequence;      /* steps with r_j <= 8: 0 store-and-revisit sweeps, 1 fused recompute passes,      */
                      /* 2 fused passes with the intermediate stored (operators without gather locality),  */
-                     /* 3 sweeps with the fp32 archive ring (SLQ_RING32 opt-in)                            */
+                     /* 3 sweeps with the fp32 archive ring (SLQ_RING32 opt-in), 4 ring-fed passes with the  */
+                     /* projections taken from Gram rows of the update passes (one gather pass fewer panel reads) */
   int pipelined;     /* dots/update passes use the pipelined row loop                                   */
   int reordered;     /* rows stored in the XCD-aware reverse Cuthill-McKee order                        */
   int upper_alpha;   /* alpha pass walks the upper triangle (exactly symmetric CSR)                     */

@@ -212,6 +212,7 @@ struct slq_plan {
   int ringR;
   bool ring_gen;              // every ring-fed pass of the plan runs k_ring_pass (always for ringR > 1; SLQ_RING_GEN for ringR = 1)
   bool ring_deep;             // steps with 4..8 ring columns run k_ring_pass with 8 waves (SLQ_RING_DEEP; else the generic passes)
+  bool gram;                  // steps with 1..8 ring columns take their projections from Gram rows of the update passes (SLQ_GRAM)
   const int32_t *rs_desc, *rs_desc_u;  // the stream the plan's ring-fed passes read (full rows / upper triangle or null)
   const char *rs_rec, *rs_rec_u;
   int32_t rs_xcd[9];
@@ -1821,7 +1822,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     // which tile stream, if any (plan_tiled): wide panels take the tiles as clustered; panels of 32 / 16 lanes per row the
     // merged tiles of the narrow-panel ring kernel (built on first use; nontemporal streams only - the one form instantiated)
     p->ringR = 0;
-    p->ring_gen = p->ring_deep = false;
+    p->ring_gen = p->ring_deep = p->gram = false;
     p->rs_desc = p->rs_desc_u = nullptr;
     p->rs_rec = p->rs_rec_u = nullptr;
     for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x];
@@ -1830,7 +1831,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->ringR = 1;
         if (op->tiles_ringed) {
           p->rs_desc = op->tile_desc, p->rs_rec = op->tile_rec, p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u;
-          p->ring_gen = p->sw.nt && env_int("SLQ_RING_GEN", 0) != 0;
+          p->ring_gen = p->sw.nt && env_int("SLQ_RING_GEN", 1) != 0;
           p->ring_deep = p->sw.nt && env_int("SLQ_RING_DEEP", 1) != 0;
         }
       } else if ((p->LPR == 32 || p->LPR == 16) && op->tiles_ringed && p->sw.nt && env_int("SLQ_RING_NARROW", 1) != 0 &&
@@ -1842,6 +1843,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u;
         for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
       }
+      // the Gram sequence needs every step of the window on k_ring_pass (PASS_UPDATEG), i.e. the deep form too
+      p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && env_int("SLQ_GRAM", 1) != 0;
     }
   }
   {
@@ -1863,8 +1866,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
 
   const size_t ring_bytes = (size_t)p->S * (size_t)p->slot_stride * p->esz;
   const size_t bp = p->bpad;
-  // alpha[deg+1], nu[orth margin for stale vectors t < 0 | deg+1], vnorm2, coefA[2], coefB, gamma[rmax]
-  const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + 1 + (size_t)p->rmax) * bp;
+  // alpha[deg+1], nu[orth margin for stale vectors t < 0 | deg+1], vnorm2, coefA[2], coefB, cross, gram[2][kFusedMaxR+1], gamma[rmax]
+  const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + 1 + 2 * (kFusedMaxR + 1) + (size_t)p->rmax) * bp;
   const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT) * bp;
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   const size_t ring32_bytes = p->ring32_on ? (size_t)p->S32 * (size_t)p->slot_stride * sizeof(float) : 0;
@@ -1905,6 +1908,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->st.coefA = s; s += 2 * bp;
   p->st.coefB = s; s += bp;
   p->st.cross = s; s += bp;
+  p->st.gram = s; s += (size_t)2 * (kFusedMaxR + 1) * bp;
   p->st.gamma = s;
   p->st.steps = p->st.active + bp;
   p->fail_d = p->st.steps + bp;
@@ -2133,7 +2137,7 @@ static int plan_sequence(const slq_plan *p) {
   const slq_operator *op = p->op;
   if (p->ring32_on) return 3;
   if (op->kind != OP_CSR || p->sw.fused == 0 || p->sw.mgs || p->nstale > 0) return 0;
-  if (p->sw.fused == 2 || op->far_per_row <= 4.0) return 1;
+  if (p->sw.fused == 2 || op->far_per_row <= 4.0) return (p->gram && p->orth >= 1 && plan_tiled(p)) ? 4 : 1;
   return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !plan_tiled(p)) ? 2 : 0;
 }
 
@@ -2543,7 +2547,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.gamma = p->st.gamma;
   a.part = p->part;
   a.bpad = p->bpad;
-  a.xt = xt | ((pass == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0);
+  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0);
   a.fail = p->ring_fail_d;
   a.dbg = debug_times_buffer();
   const bool d = p->dtype == SLQ_F64;
@@ -2657,6 +2661,20 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const int xt_a = (prev_xt && j > 0) ? 1 : 0;
       const int su = stored_u ? 2 : 0;
       const int xt_u = ((!merged && p->sw.cross) ? 1 : 0) | su;
+      // Gram sequence (ring-fed plans, r >= 1): alpha-only pass, projections from the Gram rows of the last two update passes
+      // (k_fin_gram), update pass that also takes the new vector against every ring column it reads (slq_kernels.hpp)
+      const bool gram = gen && p->gram && r >= 1 && p->nstale == 0;
+      if (gram) {
+        const int xa = j > 0 ? 1 : 0;  // (alpha_j's -beta q_j.q_{j-1} part is a Gram entry: the pass leaves W_p unread)
+        PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xa); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xa); });
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_gram, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, alpha_tiled ? p->nblkT : p->nblkF, j, r, orth_tol));
+        PROFILED(p, SLQ_K_REORTH_UPD, SLQ_TRY(launch_ring_gen(p, PASS_UPDATEG, r, gT, st, j, 0)));
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_beta_gram, dim3((bp + 63) / 64, r + 1), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkT, j, r, residual_tol));
+        prev_xt = false;
+        continue;
+      }
       if (merged) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,

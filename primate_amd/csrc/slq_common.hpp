@@ -67,7 +67,8 @@ template <typename F, int LPR> struct Geo {
   static constexpr int RPW = 64 / LPR; // rows per wave instruction
 };
 
-enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3, PASS_SPMM = 4 /* ring kernel only: k_spmm_3term's job */ };
+enum { PASS_ALPHA = 0, PASS_DOTS = 1, PASS_UPDATE = 2, PASS_ADOTS = 3, PASS_SPMM = 4 /* ring kernels only: k_spmm_3term's job */,
+       PASS_UPDATEG = 5 /* k_ring_pass only: PASS_UPDATE that also takes w against every ring column it reads (slq_ring.hpp) */ };
 
 struct TileMeta {
   const int32_t *tile_row;   // [ntiles + 1] first (stored) row of each tile

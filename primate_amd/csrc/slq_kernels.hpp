@@ -1657,6 +1657,7 @@ struct StepState {
   double *coefB;   // [bpad]        cB for sweep B
   double *gamma;   // [rmax][bpad]
   double *cross;   // [bpad]        W_{j+1} . W_j from the fused update pass (k_csr_pass xt)
+  double *gram;    // [2][kFusedMaxR + 1][bpad]  Gram rows of the last two vectors written (gram sequence): set t & 1, entry q = W_t . W_{t-q}
   int *active;     // [bpad]
   int *steps;      // [bpad]
   int bpad, nprobes, deg;
@@ -1783,6 +1784,98 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_adots(StepState st, const d
         if (fabs(sproj) > orth_tol) gm = sproj / nu;
       }
       st.gamma[(int64_t)i * st.bpad + col] = gm;
+    }
+  }
+}
+
+// ---- the Gram sequence (slq.hip: enqueue_run, ring-fed plans, 1 <= r <= kFusedMaxR) -----------------------------------------
+// The merged alpha+dots pass reads every ring column once more only to take d_i = W_t . u and g_i = W_t . W_j. Both follow
+// from inner products of ring vectors that the UPDATE pass of the step before can take on the fly, while it holds those
+// rows in registers anyway (k_ring_pass<PASS_UPDATEG>: the new vector against every column it reads):
+//   g_i = W_t . W_j                                                  is such an entry itself, and with A symmetric
+//   d_i = W_t . (sc A W_j - cp W_{j-1}) = sc (A W_t) . W_j - cp (W_t . W_{j-1}),
+//   A W_t = nu_t [ W_{t+1} + (alpha_t / nu_t) W_t + (nu_t / nu_{t-1}) W_{t-1} + (projections of step t) ]
+// (step t's own update, solved for A W_t). The projections of step t are O(eps) coefficients on vectors whose inner
+// product with W_j is O(eps) again: dropped. What is left needs G_j(s) = W_s . W_j for s = t+1, t, t-1 - inside the
+// window the update pass of step j-1 read - and W_t . W_{j-1} from the row before. The step then is an alpha-only pass
+// (one panel read: alpha_j needs the gather) + the update pass: (r + 2) panel reads + 1 write instead of (2r + 1) + 1.
+// Numerically d_i is now a difference of large terms where the merged pass took a small quantity directly; measured
+// (DESIGN.md §4.6): alpha / beta and the quadrature agree with the oracle exactly as well as before - a window of
+// 2-8 columns behind a three-term step only ever removes rounding-level components, most of them below the
+// reference's own threshold (lanczos.h:53,62).
+// k_fin_gram: blockIdx.y = i as in k_fin_adots. part: alpha partials of the alpha-only pass.
+__global__ __launch_bounds__(kFinThreads) void k_fin_gram(StepState st, const double *__restrict__ part, int nblk, int j, int RC, double orth_tol) {
+  __shared__ double red4[kFinThreads];
+  const int i = blockIdx.y;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double a_raw = sum_partials(part, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    constexpr int R1 = kFusedMaxR + 1;
+    const int64_t bp = st.bpad;
+    const double *Gc = st.gram + (int64_t)(j & 1) * R1 * bp + col;        // Gc[q * bp] = W_j . W_{j-q}
+    const double *Gp = st.gram + (int64_t)((j + 1) & 1) * R1 * bp + col;  // Gp[q * bp] = W_{j-1} . W_{j-1-q}
+    const int act = st.active[col];
+    const double nuj = st.nu[(int64_t)j * bp + col];
+    const double sc = st.coefA[col], cp = st.coefA[bp + col];
+    // alpha_j = q_j . (A q_j) - beta_j (q_j . q_{j-1}): the pass took the first dot, the second is a Gram entry
+    const double a = a_raw - (j > 0 ? sc * cp * Gc[bp] : 0.0);
+    const double cb = (act && nuj > 0.0) ? a / nuj : 0.0;
+    if (i == 0) {
+      if (act) st.alpha[(int64_t)j * bp + col] = a;
+      st.coefB[col] = cb;
+      st.gamma[col] = 0.0;
+    } else {
+      const int t = j - i;
+      const double nut = st.nu[(int64_t)t * bp + col];
+      double gm = 0.0;
+      if (act && nut > 0.0) {
+        const double g1 = Gc[(int64_t)(i - 1) * bp], g0 = Gc[(int64_t)i * bp];
+        const double alt = st.alpha[(int64_t)t * bp + col];
+        double s = g1 + (alt / nut) * g0;
+        if (t >= 1 && i + 1 <= kFusedMaxR) {
+          const double nutm = st.nu[(int64_t)(t - 1) * bp + col];
+          if (nutm > 0.0) s += (nut / nutm) * Gc[(int64_t)(i + 1) * bp];  // (zero where the window did not reach W_{t-1}: never in range, see slq.hip)
+        }
+        // W_t . W_{j-1}: t = j - 1 is the squared norm nu_{j-1}^2 itself (W_0's row is never written: take nu everywhere)
+        const double nujm = st.nu[(int64_t)(j - 1) * bp + col];
+        const double wt_wjm = i == 1 ? nujm * nujm : Gp[(int64_t)(i - 1) * bp];
+        const double d = sc * (nut * s) - cp * wt_wjm;
+        const double sproj = (d - cb * g0) / nut;
+        if (fabs(sproj) > orth_tol) gm = sproj / nut;
+      }
+      st.gamma[(int64_t)i * bp + col] = gm;
+    }
+  }
+}
+
+// After the update pass of step j in the Gram sequence: blockIdx.y = 0 does k_fin_beta's job (beta_{j+1}, stop rule, next
+// sc / cp) and stores ||W_{j+1}||^2 as entry 0 of the new Gram row; blockIdx.y = q >= 1 stores W_{j+1} . W_{j+1-q}
+// (slab q of the pass's partials; the grid has RC + 1 rows of blocks). The next step reads entries 0 .. RC only.
+__global__ __launch_bounds__(kFinThreads) void k_fin_beta_gram(StepState st, const double *__restrict__ part, int nblk, int j, int RC,
+                                                       double residual_tol) {
+  __shared__ double red4[kFinThreads];
+  constexpr int R1 = kFusedMaxR + 1;
+  const int q = blockIdx.y;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s = 0.0;
+  if (q <= RC) s = sum_partials(part + (int64_t)q * nblk * st.bpad, nblk, st.bpad, col, red4);
+  if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
+    st.gram[((int64_t)((j + 1) & 1) * R1 + q) * st.bpad + col] = s;
+    if (q == 0) {
+      double sc = 0.0, cp = 0.0;
+      if (st.active[col]) {
+        const double beta = sqrt(s);
+        st.nu[(int64_t)(j + 1) * st.bpad + col] = beta;
+        st.steps[col] = j + 1;
+        if (beta < residual_tol || (j + 1) == st.deg || !(beta == beta)) {
+          st.active[col] = 0;
+        } else {
+          sc = 1.0 / beta;
+          cp = beta / st.nu[(int64_t)j * st.bpad + col];
+        }
+      }
+      st.coefA[col] = sc;
+      st.coefA[st.bpad + col] = cp;
     }
   }
 }

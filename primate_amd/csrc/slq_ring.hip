@@ -58,6 +58,7 @@ int CAT(slq_ring_launch_, RING_TAG)(const RingArgs &a) {
     case PASS_UPDATE:
       if (rc == 0) { launch<PASS_UPDATE, 0>(a); return 0; }
       RC_SWITCH(PASS_UPDATE, launch, a) return 0;
+    case PASS_UPDATEG: RC_SWITCH(PASS_UPDATEG, launch, a) return 0;
     default: return -1;
   }
 }
@@ -68,7 +69,8 @@ hipError_t CAT(slq_ring_prepare_, RING_TAG)() {
   if (e == hipSuccess) e = prepare<PASS_UPDATE, 0>();
 #define PREP(R) \
   if (e == hipSuccess) e = prepare<PASS_ADOTS, R>(); \
-  if (e == hipSuccess) e = prepare<PASS_UPDATE, R>();
+  if (e == hipSuccess) e = prepare<PASS_UPDATE, R>(); \
+  if (e == hipSuccess) e = prepare<PASS_UPDATEG, R>();
   PREP(1) PREP(2) PREP(3) PREP(4) PREP(5) PREP(6) PREP(7) PREP(8)
 #undef PREP
   return e;
@@ -90,6 +92,13 @@ int CAT(slq_ring_vgprs_, RING_TAG)(int pass, int rc) {
       int v = -1;
 #define VG(R) if (rc == R) v = vgprs<PASS_UPDATE, R>();
       VG(0) VG(1) VG(2) VG(3) VG(4) VG(5) VG(6) VG(7) VG(8)
+#undef VG
+      return v;
+    }
+    case PASS_UPDATEG: {
+      int v = -1;
+#define VG(R) if (rc == R) v = vgprs<PASS_UPDATEG, R>();
+      VG(1) VG(2) VG(3) VG(4) VG(5) VG(6) VG(7) VG(8)
 #undef VG
       return v;
     }

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       cp[v] = (F)coefA[bpad + colbase + v];
       if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
     }
-    if (PASS == PASS_UPDATE) {
+    if (PASS == PASS_UPDATE || PASS == PASS_UPDATEG) {
 #pragma unroll
       for (int i = 0; i < RC; ++i)
 #pragma unroll
@@ -320,7 +320,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
           for (int q = 2; q < RC; ++q) w -= gm[q] * u_in[q - 2];
           stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += w * w;
-          accx += w * xc;
+          if constexpr (PASS == PASS_UPDATEG) {
+            // the new vector against every ring column the pass has in registers: the Gram row W_{j+1} . W_{j-q} from which
+            // the NEXT step's projections are assembled without reading those columns again (slq.hip: gram sequence)
+            if constexpr (RC > 0) dacc[0] += w * xc;
+            if constexpr (RC > 1) dacc[1] += w * xp;
+#pragma unroll
+            for (int q = 2; q < RC; ++q) dacc[q] += w * u_in[q - 2];
+          } else {
+            accx += w * xc;
+          }
         }
       }
     };
@@ -413,6 +422,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       reduce_out(dacc[i], part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
       reduce_out(gacc[i], part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
     }
+  } else if (PASS == PASS_UPDATEG) {
+    // slab 0: ||w||^2; slab 1 + q: w . W_{j-q}
+    reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
+#pragma unroll
+    for (int i = 0; i < RC; ++i) reduce_out(dacc[i], part + ((int64_t)(1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
   } else {
     reduce_out(acc1, part + (int64_t)blockIdx.x * bpad + panel * PW);
     if (PASS == PASS_UPDATE && xt) reduce_out(accx, part + (nblk + blockIdx.x) * bpad + panel * PW);

@@ -256,7 +256,7 @@ class LanczosPlan:
 		info = _capi.PlanInfo()
 		check(_capi.lib().slq_plan_describe(self._h, C.byref(info)))
 		d = {k: getattr(info, k) for k, _ in _capi.PlanInfo._fields_}
-		d["sequence"] = {0: "sweeps", 1: "fused", 2: "fused_stored_u", 3: "sweeps_ring32"}[d["sequence"]]
+		d["sequence"] = {0: "sweeps", 1: "fused", 2: "fused_stored_u", 3: "sweeps_ring32", 4: "fused_gram"}[d["sequence"]]
 		return d
 
 	def set_probes(self, X: np.ndarray):
