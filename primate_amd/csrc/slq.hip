@@ -2549,7 +2549,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.bpad = p->bpad;
   a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0);
   a.fail = p->ring_fail_d;
-  a.dbg = debug_times_buffer();
+  a.dbg = pass == env_int("SLQ_DEBUG_PASS", PASS_ADOTS) ? debug_times_buffer() : nullptr;  // (diagnostic builds: the pass whose time line is stamped)
   const bool d = p->dtype == SLQ_F64;
   int rc_l = -1;
   switch (p->LPR) {

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
 #ifdef SLQ_DEBUG_TIMES
       // (scripts/ring_timeline.py: workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles)
-      unsigned long long *dbg = (PASS == PASS_ADOTS && dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
+      unsigned long long *dbg = (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
       if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
 #endif
       stage_desc(k + 1);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       const int r_lo_n = lane_bcast(dnext, kDescRow0), nrows_n = more ? lane_bcast(dnext, kDescRows) : 0;
       const unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
 #ifdef SLQ_DEBUG_TIMES
-      unsigned long long *dbg = (PASS == PASS_ADOTS && dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && cw == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
+      unsigned long long *dbg = (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && cw == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
 #endif
       if constexpr (!kRefill) {
         VF xpc[MR], uc[MR][NX];

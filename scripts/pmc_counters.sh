@@ -29,7 +29,7 @@ for k, d in acc.items():
     res[k]["launches"] = n
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("launches", 0)):
-    if "k_csr_" in k or "k_spmm" in k or "k_reorth" in k or "k_axpy" in k:
+    if "k_csr_" in k or "k_ring" in k or "k_spmm" in k or "k_reorth" in k or "k_axpy" in k:
         print(k[:64], " ".join(f"{c}={v:.4g}" for c, v in d.items()))
 PY
 find $OUT -name "*.db" -delete; find $OUT -name "*_kernel_trace.csv" -delete

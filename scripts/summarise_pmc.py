@@ -34,6 +34,9 @@ def classify(name: str, orth: int):
 	m = re.search(r"k_csr_(?:ring|tile)_pass<(\w+), (\d), ", name)  # the tiled forms of the same passes: <F, PASS, ...>
 	if m:
 		return {"0": "spmm_3term", "4": "spmm_3term", "1": "reorth_dot", "3": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm"}[m.group(2)]
+	m = re.search(r"k_ring_pass<(\w+), (\d), ", name)  # slq_ring.hpp: <F, PASS, NTP, RC, LPR, WAVES>; PASS 5 = update pass with Gram rows
+	if m:
+		return {"0": "spmm_3term", "4": "spmm_3term", "3": "reorth_dot", "2": "reorth_update" if orth > 0 else "axpy_norm", "5": "reorth_update"}[m.group(2)]
 	for k, c in (("k_spmm_3term", "spmm_3term"), ("k_reorth_dot", "reorth_dot"), ("k_reorth_update", "reorth_update")):
 		if k in name:
 			return c
@@ -46,7 +49,7 @@ def classify(name: str, orth: int):
 
 summary = {"_meta": {"tag": os.path.basename(os.path.normpath(out_dir)), "kernel_sha256": kernel_sources_sha256(),
                      "collected_by": "scripts/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)"}}
-for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 30), ("lap3d_100", 3), ("lap3d_100", 0)):
+for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 6), ("lap2d_1000", 30), ("lap3d_100", 3), ("lap3d_100", 0)):
 	per = defaultdict(lambda: defaultdict(list))
 	names = {}
 	for counter in ("FETCH_SIZE", "WRITE_SIZE"):
