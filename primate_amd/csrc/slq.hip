@@ -21,6 +21,7 @@
 
 #include "slq_kernels.hpp"
 #include "slq_ring_api.h"
+#include "slq_ring.hpp"  // (RingGeo constants: no kernel of it is instantiated here)
 
 using namespace slq;
 
@@ -109,12 +110,15 @@ struct slq_operator {
   char *tile_rec = nullptr;      // the tiles' CSR records
   int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
   char *tile_rec_u = nullptr;
+  int tile_max_lines_u = 0;        // longest line list of a tile in that stream (short lists: a ring geometry with one slot more)
+  double upper_per_row = 0.0;      // distinct panel rows per row that stream lands (what decides whether the alpha-only pass takes it)
   // narrow panels (slq_ring.hpp): R = 2, 4 consecutive tiles merged into one, built the first time a plan asks for them
   // (ensure_ring_stream); [0] R = 2, [1] R = 4; *_u over the upper triangle where the operator has that stream
   struct MergedStream {
     int32_t *desc = nullptr, *desc_u = nullptr;
     char *rec = nullptr, *rec_u = nullptr;
     int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int max_lines = 0, max_lines_u = 0;  // longest line lists (full rows / upper triangle)
     bool tried = false;
   } merged[2];
   std::mutex *merged_lock = nullptr;
@@ -216,6 +220,7 @@ struct slq_plan {
   const int32_t *rs_desc, *rs_desc_u;  // the stream the plan's ring-fed passes read (full rows / upper triangle or null)
   const char *rs_rec, *rs_rec_u;
   int32_t rs_xcd[9];
+  bool ring_staged;           // the alpha-only pass's loaders go through registers (SLQ_RING_STAGED; slq_ring.hpp: GEO 1)
 };
 
 // SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
@@ -224,6 +229,7 @@ struct slq_plan {
 constexpr int kTilesDefault = 2;
 constexpr double kTileMaxColsPerRow = 4.5;      // tiles are kept when a tile row needs at most this many distinct panel rows
 constexpr double kTileAlphaColsPerRow = 2.0;    // upper-triangle tiles: the alpha-only pass takes the ring up to this many landed rows per row
+constexpr double kTileAlphaMergedColsPerRow = 2.6;  // ... and on the merged tiles of narrow panels up to this many (of the unmerged tiles)
 constexpr double kTileLevelRows = 320.0;        // level sets the tile sweep's base order should not exceed (csr_create_impl)
 
 static int env_int(const char *name, int dflt) {
@@ -1166,8 +1172,13 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         // ... which is ~24-28 GB/s per CU: worth it while the tiles land at most kTileAlphaColsPerRow panel rows
         // per row (5-point grid: 1.5 - 0.53 against 0.57 ms for the generic pass; 7-point grid: 2.5 - 0.87 against 0.82 ms)
         const double upper_per_row = (double)(tcu.size() - kCsrPad) / (double)n;
-        if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row\n", upper_per_row);
-        if (upper_per_row <= kTileAlphaColsPerRow) {
+        if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row, longest list %d (full rows: %d)\n", upper_per_row, mxu, mx);
+        op->tile_max_lines_u = mxu;
+        op->upper_per_row = upper_per_row;
+        // (built up to kTileAlphaMergedColsPerRow: wide panels take it up to kTileAlphaColsPerRow, slq_plan_create; the merged
+        // tiles of narrow panels share more of their halo and gain from it on 7-point grids too - 100^3, 64 probes: alpha pass
+        // 0.25 against 0.35 ms for the generic upper-triangle pass)
+        if (upper_per_row <= kTileAlphaMergedColsPerRow) {
           if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
           else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
           te = hipMalloc((void **)&op->tile_desc_u, desc.size() * 4);
@@ -1510,11 +1521,12 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
     }
     m.xcd_tile[8] = (int32_t)mrow.size();
     mrow.push_back((int32_t)n);
-    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d) -> bool {
+    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines) -> bool {
       std::vector<int32_t> tp, tc, lc, si, desc;
       std::vector<char> rec;
       int mx = 0;
       build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
+      *max_lines = mx;
       if (mx > kRingTileCols * R) return false;  // (cannot happen: a union of R lists of <= 36)
       if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec);
       else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec);
@@ -1523,7 +1535,7 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
       return hipMemcpy(*desc_d, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(*rec_d, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
     };
-    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec);
+    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec, &m.max_lines);
     if (ok && op->tile_desc_u && op->rowptr_u) {
       const size_t nu = (size_t)op->nnz_u;
       std::vector<int32_t> urp((size_t)n + 1), uci(nu);
@@ -1531,7 +1543,7 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
       ok = hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess &&
            hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) == hipSuccess &&
            hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) == hipSuccess &&
-           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u);
+           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u, &m.max_lines_u);
     }
     if (!ok) {
       for (void **q : {(void **)&m.desc, (void **)&m.rec, (void **)&m.desc_u, (void **)&m.rec_u}) {
@@ -1825,12 +1837,15 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     p->ring_gen = p->ring_deep = p->gram = false;
     p->rs_desc = p->rs_desc_u = nullptr;
     p->rs_rec = p->rs_rec_u = nullptr;
+    p->ring_staged = false;
     for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x];
     if (op->kind == OP_CSR && op->tiles.tile_ptr && p->sw.tiles) {
       if (p->LPR == 64) {
         p->ringR = 1;
         if (op->tiles_ringed) {
-          p->rs_desc = op->tile_desc, p->rs_rec = op->tile_rec, p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u;
+          p->rs_desc = op->tile_desc, p->rs_rec = op->tile_rec;
+          if (op->tile_desc_u && op->upper_per_row <= (double)env_int("SLQ_RING_ALPHA_MAX_X100", (int)(100 * kTileAlphaColsPerRow)) / 100.0)
+            p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u;
           p->ring_gen = p->sw.nt && env_int("SLQ_RING_GEN", 1) != 0;
           p->ring_deep = p->sw.nt && env_int("SLQ_RING_DEEP", 1) != 0;
         }
@@ -1843,6 +1858,9 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u;
         for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
       }
+      // alpha-only pass: loaders through registers on the merged tiles of narrow panels (measured: 100^3, 64 probes 0.255 -> 0.221 ms,
+      // configs[1] 0.160 -> 0.148), LDS-DMA on wide panels (0.54 against 0.56 ms). SLQ_RING_STAGED=0/1 forces either.
+      p->ring_staged = env_int("SLQ_RING_STAGED", p->ringR > 1 ? 1 : 0) != 0;
       // the Gram sequence needs every step of the window on k_ring_pass (PASS_UPDATEG), i.e. the deep form too
       p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && env_int("SLQ_GRAM", 1) != 0;
     }
@@ -2501,8 +2519,8 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
       if (op->tiles_ringed) {
         // the ring-fed variant: flag words and descriptor staging + kRingSlots slots; 16 waves per workgroup
         const size_t lds_ring = kRingHeadBytes + (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes);
-        const bool upper = PASS == PASS_ALPHA && op->tile_desc_u != nullptr && p->sw.ring_alpha == 2;
-        k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, upper ? op->tile_desc_u : op->tile_desc, upper ? op->tile_rec_u : op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
+        const bool upper = PASS == PASS_ALPHA && p->rs_desc_u != nullptr && p->sw.ring_alpha == 2;
+        k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, upper ? p->rs_desc_u : op->tile_desc, upper ? p->rs_rec_u : op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
                                                                                p->st.coefB, p->st.gamma, p->part, p->bpad,
                                                                                xt | ((PASS == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0), p->ring_fail_d);
         return;
@@ -2532,6 +2550,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   RingArgs a;
   a.pass = pass;
   a.rc = rc;
+  a.staged = (pass == PASS_ALPHA && p->ring_staged) ? 1 : 0;
   a.grid = grid;
   a.st = st;
   a.n = p->n;

@@ -19,19 +19,19 @@ constexpr int L = RING_LPR;
 // steps of up to kRingMaxR ring columns: 16 waves; more: 8 waves (256 VGPRs per wave)
 template <int PASS, int RC> constexpr int waves_of() { return RC <= kRingMaxR ? 16 : 8; }
 
-template <int PASS, int RC> void launch(const RingArgs &a) {
+template <int PASS, int RC, int GEO = 0> void launch(const RingArgs &a) {
   constexpr int W = waves_of<PASS, RC>();
-  k_ring_pass<F, PASS, 1, RC, L, W><<<a.grid, dim3(W * 64), RingGeo<L, W>::kLdsBytes, a.st>>>(
+  k_ring_pass<F, PASS, 1, RC, L, W, GEO><<<a.grid, dim3(W * 64), RingGeo<L, W, GEO>::kLdsBytes, a.st>>>(
       a.n, a.desc, a.rec, a.xr, (F *)a.ring, a.slot_stride, a.S, a.j, a.coefA, a.coefB, a.gamma, a.part, a.bpad, a.xt, a.fail, a.dbg);
 }
-template <int PASS, int RC> hipError_t prepare() {
+template <int PASS, int RC, int GEO = 0> hipError_t prepare() {
   constexpr int W = waves_of<PASS, RC>();
-  return hipFuncSetAttribute((const void *)k_ring_pass<F, PASS, 1, RC, L, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return hipFuncSetAttribute((const void *)k_ring_pass<F, PASS, 1, RC, L, W, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <int PASS, int RC> int vgprs() {
   constexpr int W = waves_of<PASS, RC>();
   hipFuncAttributes at;
-  if (hipFuncGetAttributes(&at, (const void *)k_ring_pass<F, PASS, 1, RC, L, W>) != hipSuccess) return -1;
+  if (hipFuncGetAttributes(&at, (const void *)k_ring_pass<F, PASS, 1, RC, L, W, 0>) != hipSuccess) return -1;
   return at.numRegs + ((int)(at.localSizeBytes > 0) << 16);  // bit 16: the kernel spills to scratch
 }
 
@@ -52,7 +52,10 @@ template <int PASS, int RC> int vgprs() {
 int CAT(slq_ring_launch_, RING_TAG)(const RingArgs &a) {
   const int rc = a.rc;
   switch (a.pass) {
-    case PASS_ALPHA: launch<PASS_ALPHA, 0>(a); return 0;
+    case PASS_ALPHA:
+      if (a.staged) launch<PASS_ALPHA, 0, 1>(a);  // loaders through registers instead of LDS-DMA (slq_ring.hpp: GEO 1)
+      else launch<PASS_ALPHA, 0>(a);
+      return 0;
     case PASS_SPMM: launch<PASS_SPMM, 0>(a); return 0;
     case PASS_ADOTS: RC_SWITCH(PASS_ADOTS, launch, a) return 0;
     case PASS_UPDATE:
@@ -65,6 +68,7 @@ int CAT(slq_ring_launch_, RING_TAG)(const RingArgs &a) {
 
 hipError_t CAT(slq_ring_prepare_, RING_TAG)() {
   hipError_t e = prepare<PASS_ALPHA, 0>();
+  if (e == hipSuccess) e = prepare<PASS_ALPHA, 0, 1>();
   if (e == hipSuccess) e = prepare<PASS_SPMM, 0>();
   if (e == hipSuccess) e = prepare<PASS_UPDATE, 0>();
 #define PREP(R) \

@@ -34,19 +34,30 @@ namespace slq {
 constexpr int kRingNLoaders = SLQ_RINGN_LOADERS;
 constexpr int kRingRecStride = 1536;  // bytes of record per base tile: 128 B of header + kRingTileNnz x (4 + 8)
 
-template <int LPR, int WAVES> struct RingGeo {
+// GEO 0: the tile's lines and record land by LDS-DMA (loader waves issue global_load_lds and count them with vmcnt).
+// GEO 1 ("staged"): the loader waves bring them through their REGISTERS instead (global_load_dwordx4, ds_write_b128) - for the
+// alpha-only pass. Measured (profiles/r03_tcp_counters.json): LDS-DMA lands ~25-27 GB/s per CU whatever the
+// number of loaders, slots or tiles in flight (the cadence MI355X_MICROARCH.md gives for one loader wave), and the alpha-only
+// pass - nothing but its tile images to move, 49 of the ~106 requests a CU can keep in flight - sits on that; plain vector
+// loads are not held to it (the generic gather passes move 50-58 GB/s per CU). The passes with row-local streams beside the
+// images are paced by the memory system (106 requests in flight) and keep the DMA form, which costs no registers.
+template <int LPR, int WAVES, int GEO = 0> struct RingGeo {
   static constexpr int R = 64 / LPR;                  // panel rows per wave instruction and per 1-KiB DMA
-  static constexpr int kSlots = R == 4 ? 3 : 4;       // (R = 4: four records per slot leave room for three slots)
+  static constexpr bool kStaged = GEO == 1;
+  static constexpr int kLines = kRingTileCols;        // KiB of image per slot (lines of 1 KiB / R)
   static constexpr int kRecBytes = (kRingRecStride * R + 1023) / 1024 * 1024;  // landed in whole KiB
-  static constexpr int kSlotBytes = kRingTileCols * 1024 + kRecBytes;
+  static constexpr int kSlotBytes = kLines * 1024 + kRecBytes;
   static constexpr int kFlagBytes = 64;               // ready[], done[], abort
-  // loader waves: as asked for where their descriptor staging fits beside the slots, else two
-  static constexpr int kLoaders = (WAVES == 16 && kFlagBytes + kRingNLoaders * kRingLag * R * 256 + kSlots * kSlotBytes <= 160 * 1024) ? kRingNLoaders : 2;
+  static constexpr int kSlots = (160 * 1024 - kFlagBytes - 2 * kRingLag * R * 256) / kSlotBytes;  // R = 1, 2: 4; R = 4: 3
+  static constexpr int kLag = kRingLag;               // tiles of DMAs a loader keeps in flight (it publishes tile k - kLag at tile k)
+  // loader waves: two (the A/B macro's number where their descriptor staging fits); staged: four, no staging area
+  static constexpr int kLoaders = kStaged ? (WAVES == 16 ? 4 : 2)
+                                          : ((WAVES == 16 && kFlagBytes + kRingNLoaders * kLag * R * 256 + kSlots * kSlotBytes <= 160 * 1024) ? kRingNLoaders : 2);
   static constexpr int NCW = WAVES - kLoaders;        // consumer waves
   static constexpr int G = WAVES >= 16 ? 2 : 1;       // consumer groups taking the tiles in turn
   static constexpr int NC = NCW / G;                  // consumer waves of one tile
   static constexpr int MR = (kRingTileRows + NC - 1) / NC;  // row groups (R rows each) of a tile per consumer wave
-  static constexpr int kStageBytes = kLoaders * kRingLag * R * 256;  // the loaders' descriptor staging
+  static constexpr int kStageBytes = kStaged ? 0 : kLoaders * kLag * R * 256;  // the loaders' descriptor staging
   static constexpr int kHeadBytes = kFlagBytes + kStageBytes;
   static constexpr int kLdsBytes = kHeadBytes + kSlots * kSlotBytes;
   static constexpr int kDescWords = 64 * R;           // descriptor: R blocks of 64 words (block b, word 8 + d: line d * R + b)
@@ -54,28 +65,29 @@ template <int LPR, int WAVES> struct RingGeo {
   static constexpr int kRecSelfW = 16 * R;            //   [16R .. 16R + rows) line of each row's own panel row
   static constexpr int kRecHeadB = 128 * R;           //   then the column lines (int32) and the values (F)
   static_assert(WAVES == 16 || WAVES == 8, "16 waves (<= 3 ring columns) or 8 (more)");
-  static_assert(NCW % G == 0 && kRingLag < kSlots && (2 * kSlots + 1) * 4 <= kFlagBytes, "ring geometry");  // (a slot's counters count tiles, whichever group consumed them)
+  static_assert(NCW % G == 0 && kLag + 1 <= kSlots && (2 * kSlots + 1) * 4 <= kFlagBytes, "ring geometry");  // (a slot's counters count tiles, whichever group consumed them)
   static_assert(kLdsBytes <= 160 * 1024, "the ring must fit the LDS");
   static_assert(kRecHeadB + kRingTileNnz * R * (4 + 8) <= kRecBytes, "a tile's record must fit its slot");
   static_assert(32 * R >= 16 * R + kRingTileRows * R && kRingTileRows * R < 16 * R - 1, "record header layout");
   static_assert((size_t)WAVES * 64 * 4 * 8 <= (size_t)kSlots * kSlotBytes, "the final reduction reuses the slots");
-  static_assert(((kRingTileCols + kLoaders - 1) / kLoaders + (kRecBytes + 1023) / 1024) * (kRingLag - 1) + R * kRingLag <= 56,
+  static_assert(((kLines + kLoaders - 1) / kLoaders + (kRecBytes + 1023) / 1024) * (kLag - 1) + R * kLag <= 56,
                 "a loader's DMAs in flight are counted by vmcnt");
 };
 
-template <typename F, int PASS, int NTP, int RC, int LPR, int WAVES>
+template <typename F, int PASS, int NTP, int RC, int LPR, int WAVES, int GEO = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     int n, const int32_t *__restrict__ tile_desc, const char *__restrict__ tile_rec, TileRanges xr, F *ring, int64_t slot_stride, int S, int j,
     const double *__restrict__ coefA, const double *__restrict__ coefB, const double *__restrict__ gamma, double *__restrict__ part,
     int bpad, int xt, int *__restrict__ fail, unsigned long long *dbg_base /* diagnostic builds (-DSLQ_DEBUG_TIMES) only */) {
   using VF = typename VecT<F>::type;
-  using RG = RingGeo<LPR, WAVES>;
+  using RG = RingGeo<LPR, WAVES, GEO>;
   constexpr int R = RG::R, V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
   constexpr int NX = RC > 2 ? RC - 2 : 1;
   constexpr int NC = RG::NC, MR = RG::MR, G = RG::G, NS = RG::kSlots;
   constexpr bool kRefill = G == 1;  // 8 waves: stream registers refilled in place (no second set)
   constexpr int kChunk = (R == 1 && WAVES == 16) ? kRingChunk : 2;  // (8 waves, R > 1: registers)
-  static_assert(kRingLag == 2, "the descriptor staging below holds two");
+  constexpr int LAG = RG::kLag;
+  static_assert(LAG == 2 || LAG == 3, "descriptor staging ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   using lds_int = __attribute__((address_space(3))) int;
   lds_int *flags = (lds_int *)lds_raw;
@@ -129,31 +141,110 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
   };
   // slot of the k-th tile and how many times that slot has been used before: the counters' targets. (NS may be 3: no
   // power-of-two mask; the divisions are by a constant)
-  if (ntiles > 0 && wave < RG::kLoaders) {
+  if (ntiles > 0 && wave < RG::kLoaders && RG::kStaged) {
+    // ---------------- loader, through registers (GEO 1) ----------------
+    // Every loader takes every kLoaders-th line (and record chunk) of a tile: 16 bytes per lane into a register, then one
+    // ds_write_b128 into the slot. Two register sets: the loads of tile k + 1 are issued BEFORE tile k's registers are written
+    // out, so a loader always has a tile's share in flight; descriptors are plain loads two tiles ahead. No counted waits: the
+    // compiler's own vmcnt bookkeeping (loads return in order) covers register data.
+    constexpr int NL = RG::kLoaders;
+    constexpr int MAXI = (RG::kLines + NL - 1) / NL, MAXC = (RG::kRecBytes / 1024 + NL - 1) / NL;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto fetch_desc = [&](int k, int (&d)[R]) {
+#pragma unroll
+      for (int b = 0; b < R; ++b) d[b] = tile_desc[tile_at(k) * RG::kDescWords + b * 64 + lane];
+    };
+    // (every loader issues the SAME number of loads for every tile - a share past the tile's last line or chunk loads that last
+    // one again, an L1 hit - so that the compiler can count them: with data-dependent counts it waits for vmcnt(0) before the
+    // first write-out, i.e. for the next tile's loads as well, and nothing overlaps)
+    auto issue = [&](const int (&d)[R], v4i (&buf)[MAXI + MAXC]) {
+      const int D = lane_bcast(d[0], kDescCols), nd = (D + R - 1) / R;
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) {
+        const int dd = min(wave + i * NL, nd - 1);
+        int col = lane_bcast(d[0], kDescList + dd);
+#pragma unroll
+        for (int b = 1; b < R; ++b) {
+          const int cb = lane_bcast(d[b], kDescList + dd);
+          col = g == b ? cb : col;
+        }
+        buf[i] = *(const v4i *)(wcl + (int64_t)col * PW);
+      }
+      const int chunks = lane_bcast(d[0], kDescRecChunks);
+      const char *rsrc = tile_rec + (int64_t)lane_bcast(d[0], kDescRecOff) * 16 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) buf[MAXI + i] = *(const v4i *)(rsrc + min(wave + i * NL, chunks - 1) * 1024);
+    };
+    auto put = [&](int k, const int (&d)[R], const v4i (&buf)[MAXI + MAXC]) -> bool {
+      const int slot = k % NS;
+      if (k >= NS && !spin(done + slot, NC * (k / NS))) return false;  // the slot's previous tile has been consumed
+      unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
+      const int D = lane_bcast(d[0], kDescCols), nd = (D + R - 1) / R, chunks = lane_bcast(d[0], kDescRecChunks);
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i) {
+        const int dd = wave + i * NL;
+        if (dd < nd) *(v4i *)(img + (size_t)dd * 1024 + lane * 16) = buf[i];
+      }
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = wave + i * NL;
+        if (c < chunks) *(v4i *)(img + RG::kLines * 1024 + c * 1024 + lane * 16) = buf[MAXI + i];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this loader's share is in the slot
+      if (lane == 0) bump(ready + slot);
+      return true;
+    };
+    // Order of the requests: a tile's descriptor is asked for BEFORE the loads of the tile in front of it, so that using it
+    // never waits for those (loads complete in order); and every iteration issues the same loads whether or not a next tile
+    // exists (tile_at repeats the last one), so that no count depends on control flow.
+    int da[R], db[R], dc[R], dd[R];
+    v4i ba[MAXI + MAXC], bb[MAXI + MAXC];
+    fetch_desc(0, da);
+    fetch_desc(1, db);
+    issue(da, ba);
+    for (int k = 0; k < ntiles; k += 2) {
+      fetch_desc(k + 2, dc);
+      issue(db, bb);  // tile k + 1 on its way while tile k is written out
+      if (!put(k, da, ba)) break;
+      fetch_desc(k + 3, dd);
+      issue(dc, ba);
+      if (k + 1 >= ntiles || !put(k + 1, db, bb)) break;
+#pragma unroll
+      for (int b = 0; b < R; ++b) da[b] = dc[b], db[b] = dd[b];
+    }
+  } else if (ntiles > 0 && wave < RG::kLoaders) {
     // ---------------- loader ----------------
     if (SLQ_RINGN_PRIO) __builtin_amdgcn_s_setprio(SLQ_RINGN_PRIO);
-    unsigned char *stage = lds_raw + RG::kFlagBytes + (size_t)wave * (kRingLag * R * 256);
+    unsigned char *stage = lds_raw + RG::kFlagBytes + (size_t)wave * (LAG * R * 256);
     auto stage_desc = [&](int k) {
       const int32_t *src = tile_desc + tile_at(k) * RG::kDescWords + lane;
 #pragma unroll
       for (int b = 0; b < R; ++b)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + b * 64),
-                                         (__attribute__((address_space(3))) void *)(stage + ((k & 1) * R + b) * 256), 4, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(stage + ((k % LAG) * R + b) * 256), 4, 0, 0);
     };
-    stage_desc(0);
-    int prev = 0;  // DMAs issued for tile k - 1 (the ones that may still be in flight)
+    // descriptor k is requested LAG - 1 iterations before it is used, i.e. BEFORE the DMAs of tile k - LAG + 1: everything
+    // issued after it is then exactly what the counted wait below leaves outstanding
+#pragma unroll
+    for (int i = 0; i < LAG - 1; ++i) stage_desc(i);
+    int hist[LAG - 1];  // DMAs issued for tiles k - 1, k - 2, ... (the ones that may still be in flight)
+#pragma unroll
+    for (int i = 0; i < LAG - 1; ++i) hist[i] = 0;
     bool ok = true;
-    for (int k = 0; k < ntiles + kRingLag && ok; ++k) {
+    for (int k = 0; k < ntiles + LAG && ok; ++k) {
 #ifdef SLQ_DEBUG_TIMES
       // (scripts/ring_timeline.py: workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles)
       unsigned long long *dbg = (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
       if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-      stage_desc(k + 1);
-      // descriptor k is here and tile k - 2 has landed once only what was issued after descriptor k's request is outstanding:
-      // the DMAs of tile k - 1 and the R requests of descriptor k + 1
-      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(prev + R));
-      if (k >= kRingLag && lane == 0) bump(ready + (k - kRingLag) % NS);
+      stage_desc(k + LAG - 1);
+      // descriptor k is here and tile k - LAG has landed once only what was issued after descriptor k's request is outstanding:
+      // the DMAs of tiles k - LAG + 1 .. k - 1 and the R requests of each of the LAG - 1 descriptors since
+      int since = (LAG - 1) * R;
+#pragma unroll
+      for (int i = 0; i < LAG - 1; ++i) since += hist[i];
+      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
+      if (k >= LAG && lane == 0) bump(ready + (k - LAG) % NS);
 #ifdef SLQ_DEBUG_TIMES
       if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -163,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         int dreg[R];
 #pragma unroll
         for (int b = 0; b < R; ++b)
-          asm volatile("ds_read_b32 %0, %1" : "=&v"(dreg[b]) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + ((k & 1) * R + b) * 256) + lane * 4) : "memory");
+          asm volatile("ds_read_b32 %0, %1" : "=&v"(dreg[b]) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + b) * 256) + lane * 4) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (k >= NS) ok = spin(done + slot, NC * (k / NS));  // the slot's previous tile has been consumed
 #ifdef SLQ_DEBUG_TIMES
@@ -190,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
           const char *rsrc = tile_rec + (int64_t)lane_bcast(dreg[0], kDescRecOff) * 16 + lane * 16;
           for (int c = wave; c < chunks; c += RG::kLoaders) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
-                                             (__attribute__((address_space(3))) void *)(img + kRingTileCols * 1024 + c * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(img + RG::kLines * 1024 + c * 1024), 16, 0, 0);
             ++issued;
           }
         }
@@ -201,7 +292,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         dbg[7] = (unsigned long long)issued;
       }
 #endif
-      prev = issued;
+#pragma unroll
+      for (int i = LAG - 2; i > 0; --i) hist[i] = hist[i - 1];
+      hist[0] = issued;
     }
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------
@@ -238,7 +331,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     };
     // one row group of the tile in `img`: the SpMM of the lane's row out of the image, then the pass's own arithmetic
     auto do_group = [&](const unsigned char *img, int i, int r_lo, int nrows, const VF &xp_in, const VF *u_in) {
-      const unsigned char *rec = img + kRingTileCols * 1024;
+      const unsigned char *rec = img + RG::kLines * 1024;
       const F *xl = (const F *)img + cl * V;
       const int lr = (cw + i * NC) * R + g;
       const bool live = lr < nrows;

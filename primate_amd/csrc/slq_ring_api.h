@@ -7,6 +7,7 @@
 
 struct RingArgs {
   int pass, rc;  // PASS_* of slq_kernels.hpp, ring columns of the step (compile-time variants 0..8)
+  int staged;    // PASS_ALPHA: the loader waves bring the tile through their registers instead of LDS-DMA (slq_ring.hpp: GEO 1)
   dim3 grid;
   hipStream_t st;
   int n;
