@@ -39,8 +39,10 @@ python3 $B --workload lap3d_100 --probes 64 --no-cpu-baseline --no-extra > $OUT/
 python3 $B --orth 6 --no-cpu-baseline --no-extra > $OUT/bench_orth6_line.json
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_lap3d_100_p64 -o run -- python3 $B --workload lap3d_100 --probes 64 --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench_lap3d_100_p64_line_under_rocprof.json
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_orth6 -o run -- python3 $B --orth 6 --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $OUT/bench_orth6_line_under_rocprof.json
-echo "== configs[3] and configs[4] under rocprofv3 (scripts/profile_configs.sh)"
-bash $ROOT/scripts/profile_configs.sh ${TAG}_configs
+if [ "${SKIP_CONFIGS:-0}" != "1" ]; then  # (a call of its own when the box's time limit is short: SKIP_CONFIGS=1 here, then the script itself)
+  echo "== configs[3] and configs[4] under rocprofv3 (scripts/profile_configs.sh)"
+  bash $ROOT/scripts/profile_configs.sh ${TAG}_configs
+fi
 find $OUT -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $f)); cp $f $OUT/${d}_kernel_stats.csv 2>/dev/null || true; done
 # the raw traces are large: keep summaries only
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
