@@ -159,13 +159,14 @@ struct Switches {
   int ring_rev;    // SLQ_RING_REV  the ring-fed update pass sweeps panels and tiles in reverse (it starts where the dots pass ended)
   int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
+  int dense_lds;     // SLQ_DENSE_LDS  fp64 dense product with the operands staged in LDS (k_dense_mfma_lds; 0: k_dense_mfma_tile)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
   int ring32;      // SLQ_RING32    opt-in: finished Lanczos vectors archived as fp32 for deep reorthogonalisation
   int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, pipe, ring32, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, dense_lds, pipe, ring32, fused_pad, spmm_pad})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -1785,7 +1786,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->esz = esize(op->dtype);
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
-                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 2), env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
+                   tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 2), env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_DENSE_LDS", 1) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
                    env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
@@ -2350,8 +2351,11 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
     const int ncg = p->PW >= 64 ? 2 : 1;
     const int rw = 32 * (kWaves / ncg);
     const dim3 g((p->n + rw - 1) / rw, p->NP, ks);
+    const bool lds_form = p->sw.dense_lds && (op->lda % 2 == 0);  // operands staged in LDS once per workgroup (16-byte aligned row pairs)
     for (int col0 = 0; col0 < p->PW; col0 += 32 * ncg) {  // PW = 128: two 64-column halves, A streamed twice
-      if (ncg == 2)
+      if (lds_form && ncg == 2)  // (panels of 64+ columns; 32-column panels keep the register form: their 256-row block does not fit static LDS)
+        k_dense_mfma_lds<2><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc, p->PW, col0, raw, p->slot_stride);
+      else if (ncg == 2)
         k_dense_mfma_tile<2><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc, p->PW, col0, raw, p->slot_stride);
       else
         k_dense_mfma_tile<1><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)op->vals, op->lda, (const double *)Wc, p->PW, col0, raw, p->slot_stride);

@@ -1250,6 +1250,114 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_tile(int n, const double 
       }
 }
 
+// k_dense_mfma_lds (r03): the same product with the operands staged ONCE per workgroup in LDS. k_dense_mfma_tile lets every wave
+// fetch its own fragments and leaves the repeats to the CU's L1: 16 KiB of L1 traffic per 6 KiB of unique bytes per k-quad, all of
+// it competing for the ~106 requests a CU keeps in flight - 45 % of the fp64 MFMA rate. Here a workgroup
+// (RG x NCG waves of 32 x 32 outputs, as there) walks K in stages of kDenseBK: all 512 threads bring the stage's A block
+// (kDenseBK x 32 RG, column-major like A: a wave = one column = 1 KiB) and panel block (kDenseBK x 32 NCG) into registers with
+// 16-byte loads - zero beyond n, so no size is special - while the MFMAs of the stage before run out of LDS, then store them
+// (two LDS buffers, two barriers per stage). Fragment reads are the old kernel's: one ds_read_b128 per operand gives a lane both
+// interleaved row (column) tiles; with k-strides of 1 KiB / 512 B every 16-lane group of a ds_read_b128 hits 64 distinct banks.
+// Requires lda even (16-byte aligned row pairs); slq.hip falls back to k_dense_mfma_tile otherwise.
+constexpr int kDenseBK = 16;
+template <int NCG>
+__global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *__restrict__ A, int64_t lda, const double *__restrict__ X, int ldw,
+                                                           int col0, double *__restrict__ raw, int64_t raw_stride) {
+  constexpr int RG = kWaves / NCG, BM = 32 * RG, BN = 32 * NCG, BK = kDenseBK;
+  constexpr int APT = (BK * BM / 2) / kBlock;  // 16-byte pieces of the A block per thread
+  constexpr int XPT = (BK * BN / 2 + kBlock - 1) / kBlock;
+  static_assert((BK * BM / 2) % kBlock == 0, "A block divides over the threads");
+  __shared__ __attribute__((aligned(16))) double As[2][BK][BM];
+  __shared__ __attribute__((aligned(16))) double Xs[2][BK][BN];
+  const int PW = ldw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int rg = wave / NCG, cg = wave % NCG;
+  const int panel = blockIdx.y;
+  const int rbase = blockIdx.x * BM;
+  const int64_t poff = (int64_t)panel * n * PW;
+  const double *xp = X + poff + col0;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[rt][h] = (d4_t)0.0;
+  // K range of this workgroup (gridDim.z splits K as in k_dense_mfma_tile), in stages of BK
+  const int kq_all = (n + 3) / 4;
+  const int ks = gridDim.z, kz = blockIdx.z;
+  const int perz = (kq_all + ks - 1) / ks;
+  const int k_begin = min(n, kz * perz * 4), k_end = min(n, k_begin + perz * 4);
+  const int nstage = (k_end - k_begin + BK - 1) / BK;
+  d2u_t ra[APT], rx[XPT];
+  auto fetch = [&](int st) {
+    const int k0 = k_begin + st * BK;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 2), rp = pc % (BM / 2);
+      const int k = k0 + kk, row = rbase + 2 * rp;
+      d2u_t v = (d2u_t)0.0;
+      if (k < k_end) {
+        const double *ap = A + (int64_t)k * lda + row;
+        if (row + 1 < n) v = *(const d2u_t *)ap;
+        else if (row < n) v[0] = ap[0];
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BN / 2), cp = pc % (BN / 2);
+      const int k = k0 + kk;
+      d2u_t v = (d2u_t)0.0;
+      if (pc < BK * BN / 2 && k < k_end) v = *(const d2u_t *)(xp + (int64_t)k * PW + 2 * cp);
+      rx[i] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 2), rp = pc % (BM / 2);
+      *(d2u_t *)&As[buf][kk][2 * rp] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BN / 2), cp = pc % (BN / 2);
+      if (pc < BK * BN / 2) *(d2u_t *)&Xs[buf][kk][2 * cp] = rx[i];
+    }
+  };
+  if (nstage > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) fetch(st + 1);  // in flight while this stage's MFMAs run
+#pragma unroll
+    for (int q = 0; q < BK / 4; ++q) {
+      const d2u_t a = *(const d2u_t *)&As[buf][q * 4 + lk][rg * 32 + 2 * lr];
+      const d2u_t b = *(const d2u_t *)&Xs[buf][q * 4 + lk][cg * 32 + 2 * lr];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        acc[0][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[h], acc[0][h], 0, 0, 0);
+        acc[1][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[h], acc[1][h], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nstage) stash(buf ^ 1);  // (that buffer was last read in stage st - 1: every wave is past the barrier that ended it)
+    __syncthreads();
+  }
+  double *out = raw + (int64_t)kz * raw_stride + poff;
+  const int rb = rbase + rg * 32, cbase = col0 + 32 * cg;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + 2 * (lk + 4 * r) + rt;
+        if (row < n) out[(int64_t)row * PW + cbase + 2 * lr + h] = acc[rt][h][r];
+      }
+}
+
 // Three-term epilogue for operators whose product is computed by a separate kernel (dense,
 // host callback): in: T = A (Wc) unscaled. w = sc*T - cp*Wp ; partA += (sc*Wc) * w ; Wn = w.
 template <typename F, int LPR>
