@@ -10,8 +10,9 @@ for mode in 0 default; do
   bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode} "default" "lap2d_1000:3 lap2d_1000:0 lap2d_1000:6 lap3d_100:3 lap3d_100:0 lap3d_100:6" --no-extra
   echo "== SLQ_TILES=$mode: f32, 512 probes, k = 50"
   bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode}_f32 "default" "lap2d_1400:3 lap3d_126:3" --no-extra --dtype f32 --probes 512 --deg 50
-  echo "== SLQ_TILES=$mode: narrow panel, 64 probes (tiles unused; the row order is the tiles')"
-  bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode}_p64 "default" "lap2d_1000:3 lap3d_100:3" --no-extra --probes 64
+  echo "== SLQ_TILES=$mode: narrow panels, 64 and 32 probes (merged tiles through k_ring_pass since r03; scripts/ab_ring.sh switches the new forms one by one)"
+  bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode}_p64 "default" "lap2d_1000:3 lap3d_100:3 lap2d_1000:6 lap3d_100:6" --no-extra --probes 64
+  bash $ROOT/scripts/ab_bench.sh ${TAG}_t${mode}_p32 "default" "lap2d_1000:3 lap3d_100:3" --no-extra --probes 32
   python3 - <<'PY'
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd())); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "tests"))
