@@ -157,7 +157,7 @@ struct Switches {
   int ring_alpha;  // SLQ_RING_ALPHA the alpha-only pass of a tiled symmetric operator: 2 ring over the upper-triangle stream, 1 ring over
                    //               the full rows, 0 the generic upper-triangle pass
   int ring_rev;    // SLQ_RING_REV  the ring-fed update pass sweeps panels and tiles in reverse (it starts where the dots pass ended)
-  int dense_mfma;  // SLQ_DENSE_MFMA fp64 dense operator on the matrix cores
+  int dense_mfma;  // SLQ_DENSE_MFMA dense operator on the matrix cores (fp64 and fp32)
   int dense_tile16;  // SLQ_DENSE_TILE16 keep the 16-row dense kernel also for wide panels (A/B runs)
   int dense_lds;     // SLQ_DENSE_LDS  fp64 dense product with the operands staged in LDS (k_dense_mfma_lds; 0: k_dense_mfma_tile)
   int pipe;        // SLQ_PIPE      pipelined row loop in the dots/update passes (-1: by operator, slq_plan_create)
@@ -1899,8 +1899,9 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   // also split over dense_ks workgroups whose raw products land in dense_ks slabs behind T. ks minimises the number
   // of workgroup rounds times the work per workgroup, plus a small cost per slab.
   p->dense_ks = 0;  // 0: the 16-row kernel with its fused epilogue
-  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma && p->PW >= 32 && !p->sw.dense_tile16) {
-    const int rw = 32 * (kWaves / (p->PW >= 64 ? 2 : 1));
+  const bool dense32 = op->kind == OP_DENSE && p->dtype == SLQ_F32 && p->sw.dense_mfma;  // fp32: k_dense_mfma32_lds, 256-row tiles, every panel width
+  if (dense32 || (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma && p->PW >= 32 && !p->sw.dense_tile16)) {
+    const int rw = dense32 ? kDense32BM : 32 * (kWaves / (p->PW >= 64 ? 2 : 1));
     const double wgs = (double)((p->n + rw - 1) / rw) * p->NP;
     double best = 1e30;
     const int forced = env_int("SLQ_DENSE_KSPLIT", 0);
@@ -2339,12 +2340,26 @@ extern "C" int slq_plan_get_probes(slq_plan *p, void *X, int64_t ldx) {
 }
 
 
-// fp64 dense operator on MFMA: Wn = sc*(A Wc) - cp*Wp with alpha partials (plain = 0), or Wn = A Wc
+// dense operator on MFMA (fp64, and fp32 through k_dense_mfma32_lds): Wn = sc*(A Wc) - cp*Wp with alpha partials (plain = 0), or Wn = A Wc
 static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *Wn, int first, int plain, int *nblk_out) {
   const slq_operator *op = p->op;
   hipStream_t st = p->ctx->stream;
   // panels of 32+ columns: big tiles, K split over workgroups, epilogue by k_3term_slabs (k_dense_mfma_tile);
   // 16-column panels: the 16-row kernel with its fused epilogue. SLQ_DENSE_TILE16=1 forces the latter (A/B runs).
+  if (p->dense_ks > 0 && p->dtype == SLQ_F32) {
+    const int ks = p->dense_ks;
+    float *raw = (float *)p->T + p->slot_stride;  // slabs 1..ks of T (slab 0 is the unfused product)
+    const dim3 g((p->n + kDense32BM - 1) / kDense32BM, p->NP, ks);
+    const int a_vec = op->lda % 4 == 0 && ((uintptr_t)op->vals & 15) == 0;
+    for (int col0 = 0; col0 < p->PW; col0 += kDense32BN)  // PW = 128 / 256: A streamed once per 64 columns (32 flop per byte of A: still MFMA-bound)
+      k_dense_mfma32_lds<<<g, dim3(kBlock), 0, st>>>(p->n, (const float *)op->vals, op->lda, a_vec, (const float *)Wc, p->PW, col0, raw, p->slot_stride);
+    const dim3 gS(p->nblkS, p->NP);
+    DISPATCH(SLQ_F32, p->LPR,
+             (k_3term_slabs<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n, (const F *)raw, ks, p->slot_stride, (const F *)Wc, (const F *)Wp, (F *)Wn,
+                                                             p->st.coefA, p->part, p->bpad, first, plain)));
+    if (nblk_out) *nblk_out = p->nblkS;
+    return SLQ_OK;
+  }
   if (p->dense_ks > 0) {
     const int ks = p->dense_ks;
     double *raw = (double *)p->T + p->slot_stride;  // slabs 1..ks of T (slab 0 is the unfused product)
@@ -2393,7 +2408,7 @@ static int launch_dense_mfma(slq_plan *p, const void *Wc, const void *Wp, void *
 static int apply_operator_unfused(slq_plan *p, int slot_c) {
   hipStream_t st = p->ctx->stream;
   slq_operator *op = p->op;
-  if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma) {
+  if (op->kind == OP_DENSE && p->sw.dense_mfma && (p->dtype == SLQ_F64 || p->dense_ks > 0)) {
     PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, slot_c), nullptr, p->T, 1, 1, nullptr)));
     return SLQ_OK;
   }
@@ -2752,7 +2767,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
 #undef SPMM_LAUNCH
       PROFILED(p, SLQ_K_FINALIZE,
                hipLaunchKernelGGL(k_fin_alpha, gF, dim3(kFinThreads), 0, st, p->st, p->part, p->nblkA, j, 0));
-    } else if (op->kind == OP_DENSE && p->dtype == SLQ_F64 && p->sw.dense_mfma) {
+    } else if (op->kind == OP_DENSE && p->sw.dense_mfma && (p->dtype == SLQ_F64 || p->dense_ks > 0)) {
       int nb = 0;
       PROFILED(p, SLQ_K_SPMM, SLQ_TRY(launch_dense_mfma(p, slot_ptr(p, sc_), slot_ptr(p, sp_), slot_ptr(p, sn_), first, 0, &nb)));
       PROFILED(p, SLQ_K_FINALIZE,

@@ -1358,6 +1358,114 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *
       }
 }
 
+// k_dense_mfma32_lds (r03): the fp32 dense operator on the matrix cores (reference: eigen_operators.h:24-30 with F = float,
+// _lanczos.cpp:104). v_mfma_f32_16x16x4_f32 is an exact f32 fma chain in k order (cdna_hip_programming.md §3), so the result is
+// what the VALU kernel k_dense_panel computes up to the K split; it runs at the f32 vector peak (157 TFLOP/s) with ONE register
+// per operand, where the VALU kernel re-reads the probe panel from L2 for every output row.
+// Same machine as k_dense_mfma_lds with the f32 shapes: a wave owns 32 rows x 64 columns (2 x 4 accumulator tiles; rows
+// interleaved by 2, columns by 4: fragment row m of row tile rt is row rb + 2m + rt, fragment column c of column tile h is column
+// 4c + h), so ONE ds_read_b64 gives a lane both row tiles' A elements and ONE ds_read_b128 all four column tiles' panel elements:
+// 2 LDS reads feed 8 MFMAs. A workgroup = 8 waves = 256 rows x 64 columns; K walks in stages of 16 through two LDS buffers (A
+// block 16 x 256, panel block 16 x 64), the next stage's 20 KiB in registers while this stage's 64 MFMAs per wave run. The rows
+// of the A buffer are padded by 32 words: a ds_read_b64 serves 32 lanes per pass - two k values of the fragment - and the pad
+// puts them on the two halves of the banks. Output as k_dense_mfma_lds: raw partial products in K-split slabs, summed in slab
+// order by k_3term_slabs. a_vec = 1 when A's columns are 16-byte aligned (lda % 4 == 0): 16-byte loads; else element loads.
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+typedef float f2v_t __attribute__((ext_vector_type(2)));
+constexpr int kDense32BM = 256, kDense32BN = 64, kDense32BK = 16, kDense32Pad = 32;
+__global__ __launch_bounds__(kBlock) void k_dense_mfma32_lds(int n, const float *__restrict__ A, int64_t lda, int a_vec, const float *__restrict__ X, int ldw,
+                                                             int col0, float *__restrict__ raw, int64_t raw_stride) {
+  constexpr int BM = kDense32BM, BN = kDense32BN, BK = kDense32BK, LDS_A = BM + kDense32Pad;
+  constexpr int APT = (BK * BM / 4) / kBlock;  // 16-byte pieces of the A block per thread (2); the panel block is 256 pieces: threads 0..255
+  static_assert((BK * BM / 4) % kBlock == 0 && BK * BN / 4 <= kBlock && kWaves * 32 == BM, "block shapes divide over the threads");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_A];
+  __shared__ __attribute__((aligned(16))) float Xs[2][BK][BN];
+  const int PW = ldw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int panel = blockIdx.y;
+  const int rbase = blockIdx.x * BM;
+  const int64_t poff = (int64_t)panel * n * PW;
+  const float *xp = X + poff + col0;
+  const int ncols = min(BN, PW - col0);  // panels of 16 / 32 columns: the columns beyond are fed zeros and not written
+  f4v_t acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) acc[rt][h] = (f4v_t)0.0f;
+  const int kq_all = (n + 3) / 4;
+  const int ks = gridDim.z, kz = blockIdx.z;
+  const int perz = (kq_all + ks - 1) / ks;
+  const int k_begin = min(n, kz * perz * 4), k_end = min(n, k_begin + perz * 4);
+  const int nstage = (k_end - k_begin + BK - 1) / BK;
+  f4v_t ra[APT], rx;
+  auto fetch = [&](int st) {
+    const int k0 = k_begin + st * BK;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 4), r4 = pc % (BM / 4);
+      const int k = k0 + kk, row = rbase + 4 * r4;
+      f4v_t v = (f4v_t)0.0f;
+      if (k < k_end && row < n) {
+        const float *ap = A + (int64_t)k * lda + row;
+        if (a_vec && row + 3 < n) v = *(const f4v_t *)ap;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < n) v[e] = ap[e];
+        }
+      }
+      ra[i] = v;
+    }
+    {
+      const int pc = threadIdx.x, kk = pc / (BN / 4), c4 = pc % (BN / 4);
+      const int k = k0 + kk;
+      rx = (f4v_t)0.0f;
+      if (pc < BK * BN / 4 && k < k_end && 4 * c4 < ncols) rx = *(const f4v_t *)(xp + (int64_t)k * PW + 4 * c4);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 4), r4 = pc % (BM / 4);
+      *(f4v_t *)&As[buf][kk][4 * r4] = ra[i];
+    }
+    const int pc = threadIdx.x, kk = pc / (BN / 4), c4 = pc % (BN / 4);
+    if (pc < BK * BN / 4) *(f4v_t *)&Xs[buf][kk][4 * c4] = rx;
+  };
+  if (nstage > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) fetch(st + 1);
+#pragma unroll
+    for (int q = 0; q < BK / 4; ++q) {
+      const f2v_t a = *(const f2v_t *)&As[buf][q * 4 + lk][wave * 32 + 2 * lr];
+      const f4v_t b = *(const f4v_t *)&Xs[buf][q * 4 + lk][4 * lr];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[h], acc[0][h], 0, 0, 0);
+        acc[1][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[h], acc[1][h], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nstage) stash(buf ^ 1);
+    __syncthreads();
+  }
+  // C/D of the f32 16x16x4 form: column lane & 15, row 4 (lane >> 4) + reg (the f64 form differs: cdna_hip_programming.md §3)
+  float *out = raw + (int64_t)kz * raw_stride + poff + col0 + 4 * lr;
+  const int rb = rbase + wave * 32;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rb + 2 * (4 * lk + r) + rt;
+      if (row < n && 4 * lr < ncols) *(f4v_t *)(out + (int64_t)row * PW) = (f4v_t){acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
+    }
+}
+
 // Three-term epilogue for operators whose product is computed by a separate kernel (dense,
 // host callback): in: T = A (Wc) unscaled. w = sc*T - cp*Wp ; partA += (sc*Wc) * w ; Wn = w.
 template <typename F, int LPR>

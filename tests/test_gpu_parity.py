@@ -244,6 +244,28 @@ def test_operator_products(eng):
 	np.testing.assert_allclose(eng.DeviceOperator(G.astype(np.float32)).matmat(Xg.astype(np.float32)), G @ Xg, rtol=3e-4, atol=3e-4)
 
 
+@pytest.mark.parametrize("n,P", [(516, 64), (517, 64), (700, 130), (257, 20), (300, 5), (1030, 300)])
+def test_dense_fp32_operator_on_the_matrix_cores(oracle, eng, n, P):
+	"""fp32 dense operator (eigen_operators.h:24-30 with F = float; _lanczos.cpp:104): k_dense_mfma32_lds, 256-row tiles over
+	a K split, against the oracle on the same fp32 arrays - every panel width (64 / 128 / 256 columns, two panels at P = 300),
+	aligned and unaligned leading dimensions (16-byte and element loads), ragged last row tile, a non-symmetric array."""
+	rng = np.random.default_rng(n + P)
+	B = rng.standard_normal((n, n))
+	A = (B @ B.T / n + np.eye(n)).astype(np.float32)
+	X = np.asfortranarray(rng.standard_normal((n, P)).astype(np.float32))
+	op = eng.DeviceOperator(A)
+	ref = A.astype(np.float64) @ X.astype(np.float64)
+	np.testing.assert_allclose(op.matmat(X), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())  # an f32 fma chain over K = n: ~n eps relative to sum |a x|
+	for orth in (0, 3):
+		got = eng.quad_batch(op, X, 12, orth, fun="log")
+		want = oracle.quad_batch(A, X, 12, orth, fun="log", fresh_q=True)
+		np.testing.assert_allclose(got, want, rtol=3e-4, err_msg=f"orth={orth}")
+	G = rng.standard_normal((n, n)).astype(np.float32)  # not symmetric: Y = G X, not G^T X
+	refg = G.astype(np.float64) @ X.astype(np.float64)
+	np.testing.assert_allclose(eng.DeviceOperator(G).matmat(X), refg, rtol=1e-5, atol=1e-5 * np.abs(refg).max())
+	op.close()
+
+
 def test_all_three_operator_kinds_agree_on_slq(oracle, eng):
 	A = laplacian_2d(12)
 	rng = np.random.default_rng(2)
