@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -274,13 +275,60 @@ template <typename Fn> static bool parallel_pieces(int pieces, int64_t count, Fn
 // wall time of the phases of an operator's creation, printed under SLQ_DEBUG (scripts/time_create.py)
 struct PhaseClock {
   bool on = env_int("SLQ_DEBUG", 0) != 0;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(), t0 = t;
+  void total(const char *what) {
+    if (on) fprintf(stderr, "[slq] create: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   void lap(const char *what) {
     if (!on) return;
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[slq] create: %-34s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
     t = now;
   }
+};
+
+// Uninitialised host storage for the big arrays of an operator's creation (a std::vector zero-fills them on one thread,
+// 20 ms per 100 MB, and every page is then touched a second time); whoever fills it writes every byte it will read.
+template <typename T> struct RawBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void alloc(size_t count) {
+    p.reset(new T[count]);  // (default-initialised: no fill for arithmetic T)
+    n = count;
+  }
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  size_t size() const { return n; }
+};
+
+// Host-to-device copies of an operator's arrays, run by helper threads while the caller builds the next arrays: a copy from
+// pageable memory blocks its caller at ~10 GB/s, 40 of the 160 ms a 10^6-row operator took to create. Every source must
+// outlive wait() (declare the queue AFTER the buffers it reads: its destructor joins first).
+struct UploadQueue {
+  struct Job { void *dst; const void *src; size_t bytes; };
+  int device;
+  std::vector<std::thread> th;
+  std::mutex m;
+  hipError_t err = hipSuccess;
+  explicit UploadQueue(int dev) : device(dev) {}
+  void push(std::vector<Job> jobs) {
+    th.emplace_back([this, jobs = std::move(jobs)] {
+      hipError_t e = hipSetDevice(device);
+      for (const Job &j : jobs)
+        if (e == hipSuccess && j.bytes) e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        std::lock_guard<std::mutex> g(m);
+        if (err == hipSuccess) err = e;
+      }
+    });
+  }
+  hipError_t wait() {
+    for (auto &t : th)
+      if (t.joinable()) t.join();
+    th.clear();
+    return err;
+  }
+  ~UploadQueue() { wait(); }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -514,11 +562,18 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
   // The chunks are independent (a cluster never leaves its chunk): one worker each, with its own order, its own tile
   // boundaries (counted from the chunk's first row) and its own stamp array; `assigned` is shared, but a worker reads and
   // writes the entries of its own chunk's rows only.
+  // (r03: every chunk is clustered as kClusterPieces independent halves of its order - a fixed split, so the tiles do not
+  // depend on the number of host threads - because the greedy growth is sequential and was 25-50 ms of an operator's creation
+  // with one worker per chunk; a cluster never crosses the middle of a chunk either: one short tile per 60,000 rows.)
+  constexpr int kClusterPieces = 2, NX = 8 * kClusterPieces;
   std::vector<char> assigned((size_t)n, 0);
-  std::vector<int32_t> order_x[8], rows_x[8];  // per chunk: the new order, and the row count of every cluster
-  char failed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> order_x[NX], rows_x[NX];  // per piece: the new order, and the row count of every cluster
+  char failed[NX] = {};
   auto do_chunk = [&](int x) {
-    const int64_t lo = x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+    const int64_t clo = (x / kClusterPieces) * chunk, chi = std::min<int64_t>(n, clo + chunk);
+    if (clo >= chi) return;
+    const int64_t plen = (chi - clo + kClusterPieces - 1) / kClusterPieces;
+    const int64_t lo = clo + (x % kClusterPieces) * plen, hi = std::min<int64_t>(chi, lo + plen);
     if (lo >= hi) return;
     std::vector<int32_t> stamp((size_t)n, -1);
     struct Cand { int32_t node, cnt, disc; };
@@ -574,16 +629,16 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
     }
   };
   if (host_threads() > 1) {
-    if (!parallel_pieces(8, 8, [&](int, int64_t x0, int64_t x1) { for (int64_t x = x0; x < x1; ++x) do_chunk((int)x); })) return false;
+    if (!parallel_pieces(NX, NX, [&](int, int64_t x0, int64_t x1) { for (int64_t x = x0; x < x1; ++x) do_chunk((int)x); })) return false;
   } else {
-    for (int x = 0; x < 8; ++x) do_chunk(x);
+    for (int x = 0; x < NX; ++x) do_chunk(x);
   }
   order_out.clear();
   order_out.reserve((size_t)n);
   tile_row.assign(1, 0);
-  for (int x = 0; x < 8; ++x) {
+  for (int x = 0; x < NX; ++x) {
     if (failed[x]) return false;
-    xcd_tile[x] = (int32_t)tile_row.size() - 1;
+    if (x % kClusterPieces == 0) xcd_tile[x / kClusterPieces] = (int32_t)tile_row.size() - 1;
     order_out.insert(order_out.end(), order_x[x].begin(), order_x[x].end());
     for (int32_t r : rows_x[x]) tile_row.push_back(tile_row.back() + r);
   }
@@ -713,11 +768,11 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
 template <typename F>
 static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const std::vector<int32_t> &tile_row, const std::vector<int32_t> &tile_ptr,
                               const std::vector<int32_t> &tile_cols, const std::vector<int32_t> &lcol, const std::vector<int32_t> &self_idx,
-                              std::vector<int32_t> &desc, std::vector<char> &rec) {
+                              RawBuf<int32_t> &desc, RawBuf<char> &rec) {
   const size_t ntiles = tile_row.size() - 1;
   const size_t dw = (size_t)64 * R, head_bytes = (size_t)kRecHeadBytes * R;
   const int valoff_w = 16 * R - 1, self_w = 16 * R;
-  desc.assign(ntiles * dw, 0);
+  desc.alloc(ntiles * dw);  // (zeroed tile by tile below, by the thread that fills the tile)
   // where every record starts (its size follows from the tile's nonzero count alone), then the tiles in parallel
   std::vector<size_t> off(ntiles + 1, 0);
   for (size_t t = 0; t < ntiles; ++t) {
@@ -725,13 +780,16 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
     const size_t nzp = ((size_t)nz + 3) / 4 * 4;
     off[t + 1] = off[t] + (head_bytes + nzp * 4 + nzp * sizeof(F) + 15) / 16 * 16;
   }
-  rec.assign(off[ntiles] + (size_t)kRingMetaBytes * R, 0);
+  rec.alloc(off[ntiles] + (size_t)kRingMetaBytes * R);
+  memset(rec.data() + off[ntiles], 0, (size_t)kRingMetaBytes * R);  // the spare record behind the last one
   const bool ok = parallel_pieces(host_threads(), (int64_t)ntiles, [&](int, int64_t t0, int64_t t1) {
     for (int64_t tt = t0; tt < t1; ++tt) {
       const size_t t = (size_t)tt;
       const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
       const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
       const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = head_bytes + nzp * 4, bytes = off[t + 1] - off[t];
+      memset(rec.data() + off[t], 0, bytes);
+      memset(desc.data() + t * dw, 0, dw * 4);
       int32_t *head = (int32_t *)(rec.data() + off[t]);
       for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
       head[valoff_w] = (int32_t)valoff;
@@ -854,8 +912,9 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
   const size_t es = esize(dtype);
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
-  std::vector<int32_t> rp2, ci2;
-  std::vector<char> va2;
+  std::vector<int32_t> rp2;
+  RawBuf<int32_t> ci2;
+  RawBuf<char> va2;
   // SLQ_REORDER: 0 never, 1 operators with n >= 65536, 2 always, unset = automatic. Measured (DESIGN.md
   // §5.3): on the 2-D grid of configs[1] (rms |i-j| of the nonzeros = 632 rows) it RAISED the alpha pass's
   // fetch traffic from 6.5 to 8.9 GB and the step time by 10 %; on 3-D grids (100^3: rms |i-j| = 5345,
@@ -1026,13 +1085,33 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   }
   if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
   clk.lap("reorder decision");
+  // From here on every array goes to the device through `up` while the next one is being built; the buffers it reads are
+  // declared before it and nothing returns without up.wait() (its destructor, at the latest).
+  std::vector<int32_t> inv_keep;                  // stored row of every caller row (reordered operators)
+  std::vector<int32_t> urp, uci;                  // the upper triangle (stored order), also the source of the alpha-only tile stream
+  std::vector<char> uva;
+  std::vector<int32_t> tp, tc, lc, si, tpu, tcu, lcu, siu;
+  RawBuf<int32_t> desc, desc_u;  // (the upper stream in buffers of its own: the full stream's upload is still running when it is built)
+  RawBuf<char> rec, rec_u;
+  UploadQueue up(ctx->device);
+  auto bail = [&](int code, const char *what, hipError_t e) {
+    up.wait();
+    hipStreamSynchronize(ctx->stream);
+    slq_operator_destroy(op);
+    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : code, "%s: %s", what, hipGetErrorString(e));
+  };
   if (op->perm_h) {
     std::vector<int32_t> &perm = *op->perm_h;
-    std::vector<int32_t> inv((size_t)n);
+    inv_keep.resize((size_t)n);
+    std::vector<int32_t> &inv = inv_keep;
     for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+    hipError_t pe = hipMalloc((void **)&op->perm_d, (size_t)n * 4);
+    if (pe == hipSuccess) pe = hipMalloc((void **)&op->inv_perm_d, (size_t)n * 4);
+    if (pe != hipSuccess) return bail(SLQ_EHIP, "permutation upload", pe);
+    up.push({{op->perm_d, perm.data(), (size_t)n * 4}, {op->inv_perm_d, inv.data(), (size_t)n * 4}});
     rp2.resize((size_t)n + 1);
-    ci2.resize((size_t)nnz);
-    va2.resize((size_t)nnz * es);
+    ci2.alloc((size_t)nnz);
+    va2.alloc((size_t)nnz * es);
     rp2[0] = 0;
     for (int64_t i = 0; i < n; ++i) {
       const int32_t o = perm[(size_t)i];
@@ -1047,24 +1126,31 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         std::sort(rowbuf.begin(), rowbuf.end());
         int32_t w = rp2[(size_t)i];
         for (auto &e2 : rowbuf) {
-          ci2[(size_t)w] = e2.first;
+          ci2.data()[(size_t)w] = e2.first;
           memcpy(va2.data() + (size_t)w * es, (const char *)vals + (size_t)e2.second * es, es);
           ++w;
         }
       }
     });
-    if (!pok) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+    if (!pok) {
+      up.wait();
+      slq_operator_destroy(op);
+      return fail(SLQ_ENOMEM, "host allocation failed");
+    }
     rowptr = rp2.data();
     colind = ci2.data();
     vals = va2.data();
-    hipError_t pe = hipMalloc((void **)&op->perm_d, (size_t)n * 4);
-    if (pe == hipSuccess) pe = hipMemcpyAsync(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (pe == hipSuccess) pe = hipMalloc((void **)&op->inv_perm_d, (size_t)n * 4);
-    if (pe == hipSuccess) pe = hipMemcpyAsync(op->inv_perm_d, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);  // (inv is a local)
-    if (pe != hipSuccess) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "permutation upload: %s", hipGetErrorString(pe)); }
   }
   clk.lap("permuted CSR");
+  // colind/vals carry kCsrPad spare entries: the batched row gather (slq_kernels.hpp: gather_row_uniform)
+  // loads indices and values 8 at a time and may read (never use) up to 7 entries past a row's end
+  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, ctx->stream);
+  if (e != hipSuccess) return bail(SLQ_EHIP, "CSR upload", e);
+  up.push({{op->rowptr, rowptr, (size_t)(n + 1) * 4}, {op->colind, colind, (size_t)nnz * 4}, {op->vals, vals, (size_t)nnz * es}});
   {
     // gathers per row that reach further than any cache-resident halo (|i - j| > 4096 rows in the stored
     // order): what decides between the recompute passes and the store-and-revisit sweeps (enqueue_run)
@@ -1082,28 +1168,11 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (env_int("SLQ_DEBUG", 0) != 0)
     fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=%d rms in-chunk |i-j| = %.1f, far gathers per row %.2f\n", (long long)n,
             (long long)nnz, op->perm_h ? 1 : 0, op->rms_dist, op->far_per_row);
-  // colind/vals carry kCsrPad spare entries: the batched row gather (slq_kernels.hpp: gather_row_uniform)
-  // loads indices and values 8 at a time and may read (never use) up to 7 entries past a row's end
-  hipError_t e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
-  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
-  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(op->rowptr, rowptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->colind, colind, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && nnz) e = hipMemcpyAsync(op->vals, vals, (size_t)nnz * es, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    slq_operator_destroy(op);
-    return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(e));
-  }
-  clk.lap("far count + CSR upload");
+  clk.lap("far count");
   // Symmetric operators (what Lanczos assumes; the reference never checks): the alpha pass only needs the
   // scalar q^T A q, so it can run on the upper triangle with doubled off-diagonals and gather half the
   // panel rows. Built only when the stored CSR is EXACTLY symmetric (pattern and values, sorted rows
   // without duplicates); anything else keeps the full rows. SLQ_SYM_ALPHA=0 disables it.
-  std::vector<int32_t> urp, uci;  // the upper triangle (stored order), kept for the tile stream of the alpha-only pass below
-  std::vector<char> uva;
   bool sym = false;
   if (!plain && env_int("SLQ_SYM_ALPHA", 1) != 0 && nnz > 0) {
     sym = dtype == SLQ_F64 ? build_symmetric_upper<double>(n, rowptr, colind, (const double *)vals, urp, uci, uva)
@@ -1116,22 +1185,16 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       if (ue == hipSuccess) ue = hipMalloc(&op->vals_u, (nu + kCsrPad) * es);
       if (ue == hipSuccess) ue = hipMemsetAsync(op->colind_u + nu, 0, kCsrPad * 4, ctx->stream);
       if (ue == hipSuccess) ue = hipMemsetAsync((char *)op->vals_u + nu * es, 0, kCsrPad * es, ctx->stream);
-      if (ue == hipSuccess) ue = hipMemcpyAsync(op->rowptr_u, urp.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-      if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->colind_u, uci.data(), nu * 4, hipMemcpyHostToDevice, ctx->stream);
-      if (ue == hipSuccess && nu) ue = hipMemcpyAsync(op->vals_u, uva.data(), nu * es, hipMemcpyHostToDevice, ctx->stream);
-      if (ue == hipSuccess) ue = hipStreamSynchronize(ctx->stream);
-      if (ue != hipSuccess) {
-        slq_operator_destroy(op);
-        return fail(ue == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "upper-triangle upload: %s", hipGetErrorString(ue));
-      }
+      if (ue != hipSuccess) return bail(SLQ_EHIP, "upper-triangle upload", ue);
+      up.push({{op->rowptr_u, urp.data(), (size_t)(n + 1) * 4}, {op->colind_u, uci.data(), nu * 4}, {op->vals_u, uva.data(), nu * es}});
     }
   }
   clk.lap("upper triangle");
   // workgroup tiles (SLQ_TILES): lists of the stored CSR, uploaded next to it
   if (have_tiles) {
-    std::vector<int32_t> tp, tc, lc, si;
     int mx = 0;
     build_tile_meta(n, rowptr, colind, tile_row, tp, tc, lc, si, &mx);
+    clk.lap("  tile lists");
     int32_t *d_tr = nullptr, *d_tp = nullptr, *d_tc = nullptr, *d_lc = nullptr, *d_si = nullptr;
     // (the per-nonzero lists are read by k_csr_tile_pass only: ring-sized tiles carry them inside their records instead)
     const bool lists_on_device = tiles_mode() != 2;
@@ -1140,36 +1203,37 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_tc, tc.size() * 4);
     if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_lc, lc.size() * 4);
     if (te == hipSuccess && lists_on_device) te = hipMalloc((void **)&d_si, si.size() * 4);
-    if (te == hipSuccess) te = hipMemcpyAsync(d_tr, tile_row.data(), tile_row.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess) te = hipMemcpyAsync(d_tp, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_tc, tc.data(), tc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_lc, lc.data(), lc.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess && lists_on_device) te = hipMemcpyAsync(d_si, si.data(), si.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (te == hipSuccess) te = hipStreamSynchronize(ctx->stream);
     op->tiles.tile_row = d_tr;
     op->tiles.tile_ptr = d_tp;
     op->tiles.tile_cols = d_tc;
     op->tiles.lcol = d_lc;
     op->tiles.self_idx = d_si;
+    if (te == hipSuccess) {
+      std::vector<UploadQueue::Job> jobs = {{d_tr, tile_row.data(), tile_row.size() * 4}, {d_tp, tp.data(), tp.size() * 4}};
+      if (lists_on_device) {
+        jobs.push_back({d_tc, tc.data(), tc.size() * 4});
+        jobs.push_back({d_lc, lc.data(), lc.size() * 4});
+        jobs.push_back({d_si, si.data(), si.size() * 4});
+      }
+      up.push(std::move(jobs));
+    }
     for (int x = 0; x < 9; ++x) op->tiles.xcd_tile[x] = xcd_tile[x];
     op->tiles.max_cols = mx;
     op->tiles_ringed = tiles_mode() == 2;
     if (op->tiles_ringed) op->merged_lock = new (std::nothrow) std::mutex();
     if (te == hipSuccess && op->tiles_ringed) {
-      std::vector<int32_t> desc;
-      std::vector<char> rec;
       if (dtype == SLQ_F64) build_ring_stream<double>(1, rowptr, (const double *)vals, tile_row, tp, tc, lc, si, desc, rec);
       else build_ring_stream<float>(1, rowptr, (const float *)vals, tile_row, tp, tc, lc, si, desc, rec);
+      clk.lap("  tile stream");
       te = hipMalloc((void **)&op->tile_desc, desc.size() * 4);
       if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec, rec.size());
-      if (te == hipSuccess) te = hipMemcpy(op->tile_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
-      if (te == hipSuccess) te = hipMemcpy(op->tile_rec, rec.data(), rec.size(), hipMemcpyHostToDevice);
+      if (te == hipSuccess) up.push({{op->tile_desc, desc.data(), desc.size() * 4}, {op->tile_rec, rec.data(), rec.size()}});
       if (te == hipSuccess && sym) {
         // the same tiles over the upper triangle (doubled off-diagonals), for the alpha-only pass: a tile's image then holds its
         // own rows and the neighbours of HIGHER index only - about half the halo, and the pass is bound by what it lands by DMA
-        std::vector<int32_t> tpu, tcu, lcu, siu;
         int mxu = 0;
         build_tile_meta(n, urp.data(), uci.data(), tile_row, tpu, tcu, lcu, siu, &mxu);
+        clk.lap("  upper tile lists");
         // ... which is ~24-28 GB/s per CU: worth it while the tiles land at most kTileAlphaColsPerRow panel rows
         // per row (5-point grid: 1.5 - 0.53 against 0.57 ms for the generic pass; 7-point grid: 2.5 - 0.87 against 0.82 ms)
         const double upper_per_row = (double)(tcu.size() - kCsrPad) / (double)n;
@@ -1180,21 +1244,22 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         // tiles of narrow panels share more of their halo and gain from it on 7-point grids too - 100^3, 64 probes: alpha pass
         // 0.25 against 0.35 ms for the generic upper-triangle pass)
         if (upper_per_row <= kTileAlphaMergedColsPerRow) {
-          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
-          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc, rec);
-          te = hipMalloc((void **)&op->tile_desc_u, desc.size() * 4);
-          if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec.size());
-          if (te == hipSuccess) te = hipMemcpy(op->tile_desc_u, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
-          if (te == hipSuccess) te = hipMemcpy(op->tile_rec_u, rec.data(), rec.size(), hipMemcpyHostToDevice);
+          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u);
+          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u);
+          clk.lap("  upper tile stream");
+          te = hipMalloc((void **)&op->tile_desc_u, desc_u.size() * 4);
+          if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec_u.size());
+          if (te == hipSuccess) up.push({{op->tile_desc_u, desc_u.data(), desc_u.size() * 4}, {op->tile_rec_u, rec_u.data(), rec_u.size()}});
         }
       }
     }
-    if (te != hipSuccess) {
-      slq_operator_destroy(op);
-      return fail(te == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile upload: %s", hipGetErrorString(te));
-    }
+    if (te != hipSuccess) return bail(SLQ_EHIP, "tile upload", te);
   }
-  clk.lap("tile lists + streams");
+  e = up.wait();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return bail(SLQ_EHIP, "operator upload", e);
+  clk.lap("uploads drained");
+  clk.total("all of slq_csr_create");
   *out = op;
   return SLQ_OK;
 }
@@ -1523,8 +1588,9 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
     m.xcd_tile[8] = (int32_t)mrow.size();
     mrow.push_back((int32_t)n);
     auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines) -> bool {
-      std::vector<int32_t> tp, tc, lc, si, desc;
-      std::vector<char> rec;
+      std::vector<int32_t> tp, tc, lc, si;
+      RawBuf<int32_t> desc;
+      RawBuf<char> rec;
       int mx = 0;
       build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
       *max_lines = mx;

@@ -137,8 +137,11 @@ class DeviceOperator:
 			check(L.slq_dense_create(self.ctx._h, dt, M.shape[0], ptr(M), M.shape[0], C.byref(h)))
 			self.kind, self.nnz = "dense", M.size
 		elif sp.issparse(A):
-			M = sp.csr_matrix(A).astype(self.dtype)
-			M.sort_indices()
+			M = sp.csr_matrix(A)  # (shares A's arrays when A is CSR already: nothing below writes to them)
+			if M.dtype != self.dtype:
+				M = M.astype(self.dtype)
+			if not M.has_sorted_indices:
+				M = M.sorted_indices()
 			rowptr = np.ascontiguousarray(M.indptr, dtype=np.int32)
 			colind = np.ascontiguousarray(M.indices, dtype=np.int32)
 			vals = np.ascontiguousarray(M.data, dtype=self.dtype)
