@@ -232,6 +232,9 @@ int slq_dmat_ptr(slq_dmat *m, int c0, void **dptr);
  * src/primate/random.py:100-142 (class Isotropic) without a host array. */
 int slq_dmat_generate(slq_dmat *m, int c0, int nc, int pdf, uint64_t seed, uint64_t probe_offset);
 int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int nc); /* dst[:, d0:d0+nc] = src[:, s0:s0+nc], on the device */
+/* dst[dr0:dr0+nrows, d0:d0+nc] = src[sr0:sr0+nrows, s0:s0+nc] between matrices of different heights (device to device): how a
+ * row-sharded sketch takes its rows out of full columns and back (xtrace with row-sharded sketches: trace.py:296-302 at scale) */
+int slq_dmat_copy_rows(slq_dmat *dst, int d0, int64_t dr0, slq_dmat *src, int s0, int64_t sr0, int64_t nrows, int nc);
 int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host);
 int slq_dmat_gemm_nn(slq_dmat *OUT, int o0, slq_dmat *A, int a0, int ma, const double *C_host, int mb,
                      double alpha, double beta);

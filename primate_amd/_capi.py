@@ -87,6 +87,7 @@ _SIGNATURES = {
 	"slq_device_callback_create": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P]),
 	"slq_dmat_generate": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64]),
 	"slq_dmat_copy": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
+	"slq_dmat_copy_rows": (C.c_int, [_P, C.c_int, C.c_int64, _P, C.c_int, C.c_int64, C.c_int64, C.c_int]),
 	"slq_measure_stream": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 	"slq_plan_set_probes_device": (C.c_int, [_P, _P, C.c_int64]),
 	"slq_fttr_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

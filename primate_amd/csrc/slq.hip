@@ -3260,6 +3260,21 @@ extern "C" int slq_dmat_copy(slq_dmat *dst, int d0, slq_dmat *src, int s0, int n
   return SLQ_OK;
 }
 
+// dst[dr0 : dr0 + nrows, d0 : d0 + nc] = src[sr0 : sr0 + nrows, s0 : s0 + nc]: a block of rows of some columns, between matrices
+// of different heights - what a row-sharded sketch (primate_amd.distributed) takes out of / puts into full columns.
+extern "C" int slq_dmat_copy_rows(slq_dmat *dst, int d0, int64_t dr0, slq_dmat *src, int s0, int64_t sr0, int64_t nrows, int nc) {
+  SLQ_TRY(dmat_range(dst, d0, nc, "slq_dmat_copy_rows(dst)"));
+  SLQ_TRY(dmat_range(src, s0, nc, "slq_dmat_copy_rows(src)"));
+  if (dst->ctx != src->ctx) return fail(SLQ_EINVAL, "mismatched operands");
+  if (nrows < 0 || dr0 < 0 || sr0 < 0 || dr0 + nrows > dst->n || sr0 + nrows > src->n) return fail(SLQ_EINVAL, "row range outside the matrix");
+  if (nrows == 0) return SLQ_OK;
+  HIP_TRY(hipSetDevice(dst->ctx->device));
+  HIP_TRY(hipMemcpy2DAsync(dst->d + (size_t)d0 * dst->n + dr0, (size_t)dst->n * 8, src->d + (size_t)s0 * src->n + sr0, (size_t)src->n * 8,
+                           (size_t)nrows * 8, (size_t)nc, hipMemcpyDeviceToDevice, dst->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(dst->ctx->stream));
+  return SLQ_OK;
+}
+
 extern "C" int slq_dmat_gemm_tn(slq_dmat *A, int a0, int ma, slq_dmat *B, int b0, int mb, double *C_host) {
   SLQ_TRY(dmat_range(A, a0, ma, "slq_dmat_gemm_tn(A)"));
   SLQ_TRY(dmat_range(B, b0, mb, "slq_dmat_gemm_tn(B)"));

@@ -229,16 +229,167 @@ def allgather_columns(src, ncols: int, dst, group=None):
 	dst.set(0, np.concatenate([p.numpy().T for p in parts], axis=1))
 
 
-def sharded_xtrace(M, count: int, batch: int = 128, pdf: str = "sphere", seed: int = 0, group=None, full: bool = False, device_rng: bool = True):
+def alltoall_blocks(src, dst, group=None):
+	"""dst block q = rank q's src block of this rank's number: src and dst are device matrices of `world` equal column blocks
+	(column-major, so a block is one contiguous run). Backend "nccl" (RCCL over xGMI) exchanges the device buffers in place
+	through zero-copy torch views; any other backend (gloo in the tests) stages through the host."""
+	import torch
+	import torch.distributed as dist
+
+	if dist.get_backend(group) == "nccl":
+		dev = f"cuda:{src.ctx.device}"
+		tin = torch.as_tensor(src.cuda_array(0, src.cols), device=dev)
+		tout = torch.as_tensor(dst.cuda_array(0, dst.cols), device=dev)
+		src.ctx.synchronize()  # libslq writes on its own stream
+		dist.all_to_all_single(tout, tin, group=group)
+		torch.cuda.synchronize(dev)
+		return
+	loc = torch.from_numpy(np.ascontiguousarray(src.get().T))  # (cols, rows) row-major = the column-major matrix, flat
+	out = torch.empty_like(loc)
+	dist.all_to_all_single(out, loc, group=group)
+	dst.set(0, out.numpy().T)
+
+
+def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, full: bool):
+	"""XTrace with ROW-SHARDED sketches (the estimator of src/primate/trace.py:233-315, whose n x m matrices
+	W, Q, Z at :296-302 are what grows): rank r keeps rows [r nr, (r+1) nr) of W, Q and Z - n m / world doubles each instead of
+	n m - and every tall-skinny product of the block Gram-Schmidt, of CholeskyQR2 and of the three m x m summaries is a LOCAL
+	product over those rows followed by ONE all-reduce of an m x ns or m x m matrix. The f(A)-products stay column-sharded
+	(a Lanczos run needs whole vectors): an all-to-all turns this rank's full columns into every rank's rows of them
+	(n ns / world doubles sent per rank and block, against n ns received in the replicated form's all-gather), and the
+	reverse all-to-all hands the new Q columns to the ranks that apply f(A) to them. Same estimator, same probe stream
+	(global probe ids) as `xtrace(..., device_rng=True)`; the sums run in a different order: rounding only."""
+	import torch.distributed as dist
+	from scipy.linalg import cholesky, solve_triangular
+
+	from . import engine
+	from .estimators import CountCriterion, EstimatorResult, MeanEstimator
+	from .trace import _leave_one_out_estimates
+
+	rank, world = dist.get_rank(group), dist.get_world_size(group)
+	n = M.shape[0]
+	name, kw = M._builtin
+	ctx = M._op.ctx
+	P = min(int(count), n)
+	nr = -(-n // world)  # rows per rank; the last ranks' shards are shorter (zero rows behind them: nothing to any Gram matrix)
+	rows_of = lambda q: max(0, min(nr, n - q * nr))  # noqa: E731
+	cmax = -(-int(batch) // world)  # columns per rank and block, padded to equal shards for the all-to-all
+	Wd, Qd, Zd = (engine.DeviceMatrix(nr, P, ctx=ctx) for _ in range(3))
+	Yd, Td = engine.DeviceMatrix(nr, batch, ctx=ctx), engine.DeviceMatrix(nr, batch, ctx=ctx)
+	Wfull = engine.DeviceMatrix(n, batch, ctx=ctx)  # a block's probes, whole columns (every rank draws all of them: same ids, same values)
+	Xfull, Yfull = engine.DeviceMatrix(n, cmax, ctx=ctx), engine.DeviceMatrix(n, cmax, ctx=ctx)  # this rank's columns, whole: in and out of f(A)
+	SBf, SBb, RB = (engine.DeviceMatrix(nr, cmax * world, ctx=ctx) for _ in range(3))
+	mats = (Wd, Qd, Zd, Yd, Td, Wfull, Xfull, Yfull, SBf, SBb, RB)
+	allsum = lambda X: allreduce_sum(X, group=group)  # noqa: E731
+
+	def shard(ns: int, q: int):
+		base, rem = divmod(ns, world)
+		return q * base + min(q, rem), base + (1 if q < rem else 0)
+
+	def apply_fun(src, c0: int, nloc: int):
+		"""Yfull[:, :nloc] = f(A) src[:, c0:c0+nloc] (whole columns, this rank's share of the block)"""
+		if nloc > 0:
+			plan = M._plan(nloc, True)
+			plan.set_probes_device(src.col_ptr(c0))
+			plan.run(M._rtol)
+			plan.fun_action_into(Yfull, 0, name, **kw)
+
+	def rows_from_columns(dst, o0: int, ns: int):
+		"""dst[:, o0:o0+ns] (local rows) = the block whose column shards sit in every rank's Yfull"""
+		for q in range(world):
+			SBf.copy_rows_from(q * cmax, 0, Yfull, 0, q * nr, rows_of(q), cmax)
+		alltoall_blocks(SBf, RB, group)
+		for q in range(world):
+			lo, nq = shard(ns, q)
+			if nq > 0:
+				dst.copy_from(o0 + lo, RB, q * cmax, nq)
+
+	def columns_from_rows(src, c0: int, ns: int):
+		"""Xfull[:, :nloc] (whole columns) = this rank's column shard of src[:, c0:c0+ns], whose rows are spread over the ranks"""
+		for q in range(world):
+			lo, nq = shard(ns, q)
+			if nq > 0:
+				SBb.copy_from(q * cmax, src, c0 + lo, nq)
+		alltoall_blocks(SBb, RB, group)
+		for q in range(world):
+			Xfull.copy_rows_from(0, q * nr, RB, q * cmax, 0, rows_of(q), cmax)
+
+	R, R_inv = np.zeros((0, 0)), np.zeros((0, 0))
+	result = EstimatorResult()
+	m = 0
+	try:
+		while m < P:
+			ns = min(int(batch), P - m)
+			lo, nloc = shard(ns, rank)
+			plan = M._plan(ns, True)
+			plan.generate_probes(pdf, seed=seed, probe_offset=m)
+			plan.get_probes_into(Wfull, 0)
+			Wd.copy_rows_from(m, 0, Wfull, 0, rank * nr, rows_of(rank), ns)
+			apply_fun(Wfull, lo, nloc)
+			rows_from_columns(Yd, 0, ns)
+			Cm = np.zeros((m, ns))
+			if m > 0:
+				for _ in range(2):  # block Gram-Schmidt against the existing Q, twice
+					Ci = allsum(Qd.tn(0, m, Yd, 0, ns))
+					Yd.add_product(0, Qd, 0, Ci, alpha=-1.0, beta=1.0)
+					Cm += Ci
+			## CholeskyQR2 on the row shards: the two Gram matrices are the only things exchanged
+			try:
+				R1 = cholesky(allsum(Yd.tn(0, ns, Yd, 0, ns)), lower=False)
+				Td.add_product(0, Yd, 0, solve_triangular(R1, np.eye(ns)), alpha=1.0, beta=0.0)
+				R2 = cholesky(allsum(Td.tn(0, ns, Td, 0, ns)), lower=False)
+				Qd.add_product(m, Td, 0, solve_triangular(R2, np.eye(ns)), alpha=1.0, beta=0.0)
+				Rn = R2 @ R1
+			except np.linalg.LinAlgError:
+				## numerically rank-deficient block (every rank sees the same Gram matrix, so every rank lands here together):
+				## Householder QR of the whole block on the host, every rank keeps its rows
+				Yall = np.zeros((world * nr, ns))
+				Yall[rank * nr : rank * nr + nr] = Yd.get(0, ns)
+				Qn, Rn = np.linalg.qr(allsum(Yall)[:n], mode="reduced")
+				mine = np.zeros((nr, ns))
+				mine[: rows_of(rank)] = Qn[rank * nr : rank * nr + rows_of(rank)]
+				Qd.set(m, mine)
+			R_new = np.zeros((m + ns, m + ns))
+			R_new[:m, :m], R_new[:m, m:], R_new[m:, m:] = R, Cm, Rn
+			Rn_inv = solve_triangular(Rn, np.eye(ns))
+			Ri_new = np.zeros((m + ns, m + ns))
+			Ri_new[:m, :m], Ri_new[m:, m:] = R_inv, Rn_inv
+			Ri_new[:m, m:] = -R_inv @ Cm @ Rn_inv
+			R, R_inv = R_new, Ri_new
+			columns_from_rows(Qd, m, ns)
+			apply_fun(Xfull, 0, nloc)
+			rows_from_columns(Zd, m, ns)
+			m += ns
+			## the three m x m summaries in one all-reduce
+			S3 = allsum(np.stack([Qd.tn(0, m, Wd, 0, m), Qd.tn(0, m, Zd, 0, m), Zd.tn(0, m, Wd, 0, m)]))
+			t_samples = _leave_one_out_estimates(n, S3[0], S3[1], S3[2], R, R_inv, None)
+			estimator = MeanEstimator()
+			estimator.update(t_samples.ravel())
+			result.estimator, result.estimate, result.nit = estimator, estimator.estimate, m
+	finally:
+		for d in mats:
+			d.close()
+	result.criterion = CountCriterion(count=P)
+	return (result.estimate, result) if full else result.estimate
+
+
+def sharded_xtrace(M, count: int, batch: int = 128, pdf: str = "sphere", seed: int = 0, group=None, full: bool = False, device_rng: bool = True, sketches: str = "replicated"):
 	"""XTrace of a device `MatrixFunction` with the f(A)-products of every block split by column over the
 	ranks of `group` (BASELINE.json configs[2]: "512 probes, 1 -> 8 GPUs probe-sharded"). Every rank must
 	call it with the same arguments; every rank returns the same estimate. Two all-gathers of n x batch
 	doubles per block (Y = f(A) W and Z = f(A) Q_new) are the only collectives; the sample matrix W is
-	replicated without communication because all ranks draw it from the same (seed, probe id) stream."""
+	replicated without communication because all ranks draw it from the same (seed, probe id) stream.
+	sketches="rows": the n x m sketches W, Q, Z are ROW-sharded instead (`_xtrace_row_sharded`: 1/world of the memory and of the
+	Gram-matrix work per rank, one m x m all-reduce per Gram matrix, all-to-alls instead of all-gathers) - for n m beyond one
+	GPU's HBM or blocks wide enough for the dense algebra to matter; needs the device probe stream."""
 	import torch.distributed as dist
 
 	from .trace import xtrace
 
+	assert sketches in ("replicated", "rows"), "sketches is 'replicated' or 'rows'"
+	if sketches == "rows" and dist.is_initialized():  # (also for a world of one: the same code path, its collectives included)
+		assert device_rng and isinstance(pdf, str), "row-sharded sketches draw their probes on the device"
+		return _xtrace_row_sharded(M, count, batch, pdf, int(seed), group, full)
 	if not dist.is_initialized() or dist.get_world_size(group) == 1:
 		return xtrace(M, batch=batch, pdf=pdf, seed=seed, count=count, full=full, device_rng=device_rng)
 	rank, world = dist.get_rank(group), dist.get_world_size(group)

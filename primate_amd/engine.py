@@ -538,6 +538,10 @@ class DeviceMatrix:
 		"""self[:, d0:d0+nc] = src[:, s0:s0+nc] (device to device)."""
 		check(_capi.lib().slq_dmat_copy(self._h, int(d0), src._h, int(s0), int(nc)))
 
+	def copy_rows_from(self, d0: int, dr0: int, src: "DeviceMatrix", s0: int, sr0: int, nrows: int, nc: int):
+		"""self[dr0:dr0+nrows, d0:d0+nc] = src[sr0:sr0+nrows, s0:s0+nc] (device to device; the matrices may differ in height)."""
+		check(_capi.lib().slq_dmat_copy_rows(self._h, int(d0), int(dr0), src._h, int(s0), int(sr0), int(nrows), int(nc)))
+
 	def cuda_array(self, c0: int, nc: int):
 		"""Columns [c0, c0+nc) as a flat object with `__cuda_array_interface__` (zero-copy view for
 		torch.as_tensor(..., device="cuda"): the RCCL collectives of primate_amd.distributed)."""

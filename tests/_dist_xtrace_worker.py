@@ -39,6 +39,9 @@ def main():
 	## ragged on purpose: 50 probes in blocks of 20 (20, 20, 10) over `world` ranks
 	est, info = sharded_xtrace(M, count=50, batch=20, pdf="sphere", seed=7, full=True)
 	res["estimate"], res["nit"] = float(est), int(info.nit)
+	## the same estimator with the sketches row-sharded (all-to-alls + m x m all-reduces instead of all-gathers)
+	est, info = sharded_xtrace(M, count=50, batch=20, pdf="sphere", seed=7, full=True, sketches="rows")
+	res["estimate_rows"], res["nit_rows"] = float(est), int(info.nit)
 	## probe-sharded hutch and diag on the same operator: one reduction each
 	cnt, mean, var = sharded_hutch_device(M._op, 45, 20, 3, fun="exp", seed=13, t=-0.5)
 	res["hutch"] = [int(cnt), float(mean), float(var)]

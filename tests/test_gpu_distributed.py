@@ -40,6 +40,9 @@ def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
 	res = _launch(world, "gloo", tmp_path / f"g{world}", port, share_gpu0=True)
 	assert all(r["gather_ok"] and r["nit"] == 50 for r in res)
 	assert len({r["estimate"] for r in res}) == 1  # replicated algebra on identical inputs
+	## row-sharded sketches (world = 3: 1600 rows -> 534, 534, 532): every rank the same number, equal to one process to rounding
+	assert all(r["nit_rows"] == 50 for r in res) and len({r["estimate_rows"] for r in res}) == 1
+	assert res[0]["estimate_rows"] == pytest.approx(single, rel=1e-9)
 	## probe-sharded hutch / diag: global probe ids, so the pooled statistics equal the single-process ones
 	from primate_amd.distributed import sharded_diag_device, sharded_hutch_device
 
@@ -63,7 +66,8 @@ def test_sharded_xtrace_ranks_match_single_process(tmp_path, world, port):
 
 def test_rccl_allgather_code_path_world_of_one(tmp_path):
 	res = _launch(1, "nccl", tmp_path / "n1", 29532, share_gpu0=False)
-	assert res[0]["gather_ok"] and res[0]["nit"] == 50
+	assert res[0]["gather_ok"] and res[0]["nit"] == 50 and res[0]["nit_rows"] == 50  # (all_gather_into_tensor and all_to_all_single on libslq's buffers)
+	assert res[0]["estimate_rows"] == pytest.approx(res[0]["estimate"], rel=1e-9)
 
 
 def test_rccl_two_ranks_two_gpus(tmp_path):
@@ -83,3 +87,4 @@ def test_rccl_two_ranks_two_gpus(tmp_path):
 	res = _launch(2, "nccl", tmp_path / "n2", 29535, share_gpu0=False)
 	assert all(r["gather_ok"] and r["nit"] == 50 for r in res)
 	assert len({r["estimate"] for r in res}) == 1 and res[0]["estimate"] == pytest.approx(single, rel=1e-9)
+	assert len({r["estimate_rows"] for r in res}) == 1 and res[0]["estimate_rows"] == pytest.approx(single, rel=1e-9)
