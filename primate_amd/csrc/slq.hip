@@ -112,6 +112,7 @@ struct slq_operator {
   int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
   char *tile_rec_u = nullptr;
   int tile_max_lines_u = 0;        // longest line list of a tile in that stream (short lists: a ring geometry with one slot more)
+  bool tile_u_padded = false;      // ... with every row's entries padded to a multiple of four (build_ring_stream: pad_rows)
   double upper_per_row = 0.0;      // distinct panel rows per row that stream lands (what decides whether the alpha-only pass takes it)
   // narrow panels (slq_ring.hpp): R = 2, 4 consecutive tiles merged into one, built the first time a plan asks for them
   // (ensure_ring_stream); [0] R = 2, [1] R = 4; *_u over the upper triangle where the operator has that stream
@@ -230,7 +231,7 @@ struct slq_plan {
 // is created (whether its passes use them).
 constexpr int kTilesDefault = 2;
 constexpr double kTileMaxColsPerRow = 4.5;      // tiles are kept when a tile row needs at most this many distinct panel rows
-constexpr double kTileAlphaColsPerRow = 2.0;    // upper-triangle tiles: the alpha-only pass takes the ring up to this many landed rows per row
+constexpr double kTileAlphaColsPerRow = 2.6;    // upper-triangle tiles: the alpha-only pass takes the ring up to this many landed rows per row (r03: 7-point grids too)
 constexpr double kTileAlphaMergedColsPerRow = 2.6;  // ... and on the merged tiles of narrow panels up to this many (of the unmerged tiles)
 constexpr double kTileLevelRows = 320.0;        // level sets the tile sweep's base order should not exceed (csr_create_impl)
 
@@ -768,16 +769,35 @@ static void build_tile_meta(int64_t n, const int32_t *rowptr, const int32_t *col
 template <typename F>
 static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const std::vector<int32_t> &tile_row, const std::vector<int32_t> &tile_ptr,
                               const std::vector<int32_t> &tile_cols, const std::vector<int32_t> &lcol, const std::vector<int32_t> &self_idx,
-                              RawBuf<int32_t> &desc, RawBuf<char> &rec) {
+                              RawBuf<int32_t> &desc, RawBuf<char> &rec, bool *pad_rows = nullptr) {
   const size_t ntiles = tile_row.size() - 1;
   const size_t dw = (size_t)64 * R, head_bytes = (size_t)kRecHeadBytes * R;
   const int valoff_w = 16 * R - 1, self_w = 16 * R;
   desc.alloc(ntiles * dw);  // (zeroed tile by tile below, by the thread that fills the tile)
-  // where every record starts (its size follows from the tile's nonzero count alone), then the tiles in parallel
+  // *pad_rows (R = 1, the alpha-only pass's stream): every row's entries padded to a multiple of four, at least four, with
+  // {the row's own line, 0} - its consumer then reads a row's entries four at a time with aligned 16-byte LDS reads and
+  // without a single per-entry condition (slq_ring.hpp: do_alpha_padded). Given up (*pad_rows = false) if some tile's record
+  // would outgrow its slot.
+  bool pad = pad_rows && *pad_rows && R == 1;
+  auto padded = [](int32_t cnt) { return std::max<int32_t>(4, (cnt + 3) / 4 * 4); };
+  if (pad) {
+    for (size_t t = 0; t < ntiles && pad; ++t) {
+      size_t e = 0;
+      for (int32_t r = tile_row[t]; r < tile_row[t + 1]; ++r) e += (size_t)padded(rowptr[r + 1] - rowptr[r]);
+      if (head_bytes + e * (4 + sizeof(F)) > (size_t)((kRingRecStride * R + 1023) / 1024 * 1024)) pad = false;
+    }
+  }
+  if (pad_rows) *pad_rows = pad;
+  // where every record starts (its size follows from the tile's entry count alone), then the tiles in parallel
   std::vector<size_t> off(ntiles + 1, 0);
   for (size_t t = 0; t < ntiles; ++t) {
-    const int32_t r0 = tile_row[t], nz = rowptr[tile_row[t + 1]] - rowptr[r0];
-    const size_t nzp = ((size_t)nz + 3) / 4 * 4;
+    const int32_t r0 = tile_row[t];
+    size_t nz = (size_t)(rowptr[tile_row[t + 1]] - rowptr[r0]);
+    if (pad) {
+      nz = 0;
+      for (int32_t r = r0; r < tile_row[t + 1]; ++r) nz += (size_t)padded(rowptr[r + 1] - rowptr[r]);
+    }
+    const size_t nzp = (nz + 3) / 4 * 4;
     off[t + 1] = off[t] + (head_bytes + nzp * 4 + nzp * sizeof(F) + 15) / 16 * 16;
   }
   rec.alloc(off[ntiles] + (size_t)kRingMetaBytes * R);
@@ -785,17 +805,38 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
   const bool ok = parallel_pieces(host_threads(), (int64_t)ntiles, [&](int, int64_t t0, int64_t t1) {
     for (int64_t tt = t0; tt < t1; ++tt) {
       const size_t t = (size_t)tt;
-      const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0], nz = rowptr[r0 + rows] - p0;
+      const int32_t r0 = tile_row[t], rows = tile_row[t + 1] - r0, p0 = rowptr[r0];
+      int32_t nz = rowptr[r0 + rows] - p0;
+      if (pad) {
+        nz = 0;
+        for (int32_t i = 0; i < rows; ++i) nz += padded(rowptr[r0 + i + 1] - rowptr[r0 + i]);
+      }
       const int32_t D = tile_ptr[t + 1] - tile_ptr[t];
       const size_t nzp = ((size_t)nz + 3) / 4 * 4, valoff = head_bytes + nzp * 4, bytes = off[t + 1] - off[t];
       memset(rec.data() + off[t], 0, bytes);
       memset(desc.data() + t * dw, 0, dw * 4);
       int32_t *head = (int32_t *)(rec.data() + off[t]);
-      for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
       head[valoff_w] = (int32_t)valoff;
       for (int32_t i = 0; i < rows; ++i) head[self_w + i] = self_idx[(size_t)(r0 + i)];
-      memcpy(rec.data() + off[t] + head_bytes, lcol.data() + p0, (size_t)nz * 4);
-      memcpy(rec.data() + off[t] + valoff, vals + p0, (size_t)nz * sizeof(F));
+      if (!pad) {
+        for (int32_t i = 0; i <= rows; ++i) head[i] = rowptr[r0 + i] - p0;
+        memcpy(rec.data() + off[t] + head_bytes, lcol.data() + p0, (size_t)nz * 4);
+        memcpy(rec.data() + off[t] + valoff, vals + p0, (size_t)nz * sizeof(F));
+      } else {
+        int32_t *lc_out = (int32_t *)(rec.data() + off[t] + head_bytes);
+        F *va_out = (F *)(rec.data() + off[t] + valoff);
+        int32_t w = 0;
+        for (int32_t i = 0; i < rows; ++i) {
+          const int32_t q0 = rowptr[r0 + i], cnt = rowptr[r0 + i + 1] - q0, pc = padded(cnt);
+          head[i] = w;
+          for (int32_t q = 0; q < pc; ++q) {
+            lc_out[w + q] = q < cnt ? lcol[(size_t)(q0 + q)] : self_idx[(size_t)(r0 + i)];
+            va_out[w + q] = q < cnt ? vals[q0 + q] : (F)0;
+          }
+          w += pc;
+        }
+        head[rows] = w;
+      }
       int32_t *d = desc.data() + t * dw;
       d[kDescCols] = D;
       d[kDescRecOff] = (int32_t)(off[t] / 16);
@@ -1234,8 +1275,9 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         int mxu = 0;
         build_tile_meta(n, urp.data(), uci.data(), tile_row, tpu, tcu, lcu, siu, &mxu);
         clk.lap("  upper tile lists");
-        // ... which is ~24-28 GB/s per CU: worth it while the tiles land at most kTileAlphaColsPerRow panel rows
-        // per row (5-point grid: 1.5 - 0.53 against 0.57 ms for the generic pass; 7-point grid: 2.5 - 0.87 against 0.82 ms)
+        // Worth it while the tiles land at most kTileAlphaColsPerRow panel rows per row (r03, scalar-descriptor loaders and the
+        // padded-row consumer of slq_ring.hpp: 5-point grid, 1.5 rows per row: 0.40 against 0.51 ms for the generic pass; 7-point
+        // grid, 2.5: 0.66 against 0.81 ms)
         const double upper_per_row = (double)(tcu.size() - kCsrPad) / (double)n;
         if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row, longest list %d (full rows: %d)\n", upper_per_row, mxu, mx);
         op->tile_max_lines_u = mxu;
@@ -1244,8 +1286,10 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         // tiles of narrow panels share more of their halo and gain from it on 7-point grids too - 100^3, 64 probes: alpha pass
         // 0.25 against 0.35 ms for the generic upper-triangle pass)
         if (upper_per_row <= kTileAlphaMergedColsPerRow) {
-          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u);
-          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u);
+          bool pad = env_int("SLQ_RING_PAD_ROWS", 1) != 0;
+          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
+          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
+          op->tile_u_padded = pad;
           clk.lap("  upper tile stream");
           te = hipMalloc((void **)&op->tile_desc_u, desc_u.size() * 4);
           if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec_u.size());
@@ -2651,7 +2695,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.gamma = p->st.gamma;
   a.part = p->part;
   a.bpad = p->bpad;
-  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0);
+  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0) | ((upper && p->ringR == 1 && p->op->tile_u_padded) ? 8 : 0);  // bit 3: padded rows
   a.fail = p->ring_fail_d;
   a.dbg = pass == env_int("SLQ_DEBUG_PASS", PASS_ADOTS) ? debug_times_buffer() : nullptr;  // (diagnostic builds: the pass whose time line is stamped)
   const bool d = p->dtype == SLQ_F64;

@@ -136,18 +136,81 @@ static_assert((size_t)kRingWaves * 64 * 4 * 8 <= (size_t)kRingSlots * (kRingTile
 static_assert(kRecHeadBytes + ((kRingTileNnz + 3) / 4 * 4) * (4 + 8) <= kRingMetaBytes, "a tile's record must fit its slot");
 static_assert(((kRingTileCols + kRingLoaders - 1) / kRingLoaders + 2) * kRingLag + 1 <= 63, "a loader's DMAs in flight are counted by vmcnt");
 
-// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate, so n indexes a table of 57
+// {s_waitcnt, s_branch} pairs (8 bytes each) entered by a computed s_setpc - seven scalar instructions whatever n is. (A `switch`
+// over the cases, and a tree of ifs as well, compiled into chains of compares and branches, up to ~100 instructions per call:
+// a quarter of a ring loader's time per tile, r03 scripts/ring_timeline.py.) s[98:99] and SCC are clobbered.
 __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
-#define SLQ_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n < 0 ? 0 : n) {
-    SLQ_VM(0) SLQ_VM(1) SLQ_VM(2) SLQ_VM(3) SLQ_VM(4) SLQ_VM(5) SLQ_VM(6) SLQ_VM(7) SLQ_VM(8) SLQ_VM(9) SLQ_VM(10) SLQ_VM(11)
-    SLQ_VM(12) SLQ_VM(13) SLQ_VM(14) SLQ_VM(15) SLQ_VM(16) SLQ_VM(17) SLQ_VM(18) SLQ_VM(19) SLQ_VM(20) SLQ_VM(21) SLQ_VM(22)
-    SLQ_VM(23) SLQ_VM(24) SLQ_VM(25) SLQ_VM(26) SLQ_VM(27) SLQ_VM(28) SLQ_VM(29) SLQ_VM(30) SLQ_VM(31) SLQ_VM(32) SLQ_VM(33)
-    SLQ_VM(34) SLQ_VM(35) SLQ_VM(36) SLQ_VM(37) SLQ_VM(38) SLQ_VM(39) SLQ_VM(40) SLQ_VM(41) SLQ_VM(42) SLQ_VM(43) SLQ_VM(44)
-    SLQ_VM(45) SLQ_VM(46) SLQ_VM(47) SLQ_VM(48) SLQ_VM(49) SLQ_VM(50) SLQ_VM(51) SLQ_VM(52) SLQ_VM(53) SLQ_VM(54) SLQ_VM(55)
-    default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;  // a stricter wait than asked for is always safe
-  }
-#undef SLQ_VM
+  int t = __builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > 56 ? 56 : n));  // (a stricter wait than asked for is always safe)
+  asm volatile(
+      "s_lshl_b32 %0, %0, 3\n\t"
+      "s_getpc_b64 s[98:99]\n\t"      // the address of the next instruction; the table starts 20 bytes (five instructions) further
+      "s_add_u32 s98, s98, %0\n\t"
+      "s_addc_u32 s99, s99, 0\n\t"
+      "s_add_u32 s98, s98, 20\n\t"
+      "s_addc_u32 s99, s99, 0\n\t"
+      "s_setpc_b64 s[98:99]\n\t"
+      "s_waitcnt vmcnt(0)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(1)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(2)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(3)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(4)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(5)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(6)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(7)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(8)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(9)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(10)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(11)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(12)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(13)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(14)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(15)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(16)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(17)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(18)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(19)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(20)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(21)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(22)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(23)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(24)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(25)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(26)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(27)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(28)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(29)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(30)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(31)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(32)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(33)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(34)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(35)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(36)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(37)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(38)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(39)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(40)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(41)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(42)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(43)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(44)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(45)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(46)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(47)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(48)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(49)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(50)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(51)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(52)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(53)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(54)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(55)\n\ts_branch .Lslq_vmw%=\n\t"
+      "s_waitcnt vmcnt(56)\n"
+      ".Lslq_vmw%=:"
+      : "+s"(t)
+      :
+      : "memory", "s98", "s99", "scc");
 }
 
 // broadcast lane `l` (wave-uniform) of a value held one entry per lane

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
   const int rev = (xt >> 2) & 1;
   const int panel = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
+  const int padded_rows = (xt >> 3) & 1;  // the stream's rows are padded to whole chunks of four entries (slq.hip: build_ring_stream)
   xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wcl = ring + (int64_t)(j % S) * slot_stride + poff;
@@ -212,8 +213,107 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
 #pragma unroll
       for (int b = 0; b < R; ++b) da[b] = dc[b], db[b] = dd[b];
     }
+  } else if (ntiles > 0 && wave < RG::kLoaders && R == 1) {
+    // ---------------- loader, whole-row panels (R = 1) ----------------
+    // A loader's own instruction stream was a tile period of the alpha-only pass (r03, scripts/ring_timeline.py: ~50 ns per DMA - a
+    // v_readlane, two scalar shifts, a 64-bit VALU add and the M0 write per line, behind an LDS-staged descriptor - plus two LDS
+    // round trips and a 100-instruction vmcnt switch per tile). Here the descriptor comes by SCALAR loads (one tile ahead, straight
+    // into SGPRs: no staging DMAs to count, no LDS read, no readlane), a line's source is an SGPR base + the lane's constant
+    // 16-byte offset, and the `done` counter of the next tile's slot is read behind this tile's DMAs and waited for after the
+    // counted wait that follows. Order of a loader's requests: T0 w0 T1 w1 T2 ...; w_k leaves the DMAs of tiles k + 2 - LAG .. k
+    // outstanding, so tile k + 1 - LAG has landed and is published. (The loop is rotated - tile k's DMAs first, then everything that
+    // precedes tile k + 1's - so that the read-ahead registers are waited for in the iteration that loads them.)
+    if (SLQ_RINGN_PRIO) __builtin_amdgcn_s_setprio(SLQ_RINGN_PRIO);
+    constexpr int MAXU = (RG::kLines + RG::kLoaders - 1) / RG::kLoaders;  // lines of a tile per loader at most
+    const char *wbase = (const char *)(ring + (int64_t)(j % S) * slot_stride + (int64_t)panel * n * PW);  // (wave-uniform)
+    const unsigned lane_off = (unsigned)lane * 16u;
+    struct TileDesc {
+      int D, recoff, chunks;
+      int c[MAXU];
+    };
+    auto fetch_desc = [&](int k, TileDesc &o) {  // uniform addresses: s_load
+      const int32_t *dsc = tile_desc + tile_at(k) * RG::kDescWords;
+      o.D = dsc[kDescCols];
+      o.recoff = dsc[kDescRecOff];
+      o.chunks = dsc[kDescRecChunks];
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) o.c[u] = dsc[kDescList + wave + u * RG::kLoaders];
+    };
+    TileDesc cur;
+    fetch_desc(0, cur);
+    int dv = 0, ab = 0;
+    int hist[LAG - 1];  // DMAs issued for tiles k, k - 1, ... (the ones that may still be in flight before tile k + 1)
+#pragma unroll
+    for (int i = 0; i < LAG - 1; ++i) hist[i] = 0;
+    bool ok = true;
+#ifdef SLQ_DEBUG_TIMES
+    auto dbg_of = [&](int k) -> unsigned long long * {
+      return (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256 && lane == 0) ? dbg_base + (size_t)k * 8 : nullptr;
+    };
+    if (auto *q = dbg_of(0)) q[0] = q[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int k = 0; k < ntiles + LAG - 1 && ok; ++k) {
+      int issued = 0;
+      if (k < ntiles) {
+        const int slot = k % NS;
+        if (k >= NS) {  // the slot's previous tile has been consumed? (usually known from the read-ahead; else poll)
+          if (__builtin_amdgcn_readfirstlane(ab)) ok = false;
+          else if (__builtin_amdgcn_readfirstlane(dv) < NC * (k / NS)) ok = spin(done + slot, NC * (k / NS));
+        }
+#ifdef SLQ_DEBUG_TIMES
+        if (auto *q = dbg_of(k)) q[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (ok) {
+          unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
+          const int nd = cur.D;
+#pragma unroll
+          for (int u = 0; u < MAXU; ++u) {
+            const int d = wave + u * RG::kLoaders;
+            if (d < nd) {
+              const int col = cur.c[u];
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wbase + (int64_t)col * (PW * (int)sizeof(F)) + lane_off),
+                                               (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
+              ++issued;
+            }
+          }
+          const char *rsrc = tile_rec + (int64_t)cur.recoff * 16;
+          for (int c = wave; c < cur.chunks; c += RG::kLoaders) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024 + lane_off),
+                                             (__attribute__((address_space(3))) void *)(img + RG::kLines * 1024 + c * 1024), 16, 0, 0);
+            ++issued;
+          }
+        }
+      }
+#ifdef SLQ_DEBUG_TIMES
+      if (auto *q = dbg_of(k)) {
+        q[3] = __builtin_amdgcn_s_memrealtime();
+        q[7] = (unsigned long long)issued;
+      }
+      if (auto *q = dbg_of(k + 1)) q[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+      // ---- what precedes tile k + 1 ----
+      TileDesc nxt;
+      fetch_desc(k + 1, nxt);
+      int dvn, abn;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(dvn), "=&v"(abn) : "v"((unsigned)(uintptr_t)(done + (k + 1) % NS)), "v"((unsigned)(uintptr_t)abort_f) : "memory");
+#pragma unroll
+      for (int i = LAG - 2; i > 0; --i) hist[i] = hist[i - 1];
+      hist[0] = issued;
+      int since = 0;
+#pragma unroll
+      for (int i = 0; i < LAG - 1; ++i) since += hist[i];
+      wait_vmcnt_at_most(since);
+      if (k + 1 >= LAG && lane == 0) bump(ready + (k + 1 - LAG) % NS);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dvn), "+v"(abn)::"memory");
+      dv = dvn;
+      ab = abn;
+      cur = nxt;
+#ifdef SLQ_DEBUG_TIMES
+      if (auto *q = dbg_of(k + 1)) q[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
   } else if (ntiles > 0 && wave < RG::kLoaders) {
-    // ---------------- loader ----------------
+    // ---------------- loader, merged tiles (R > 1): descriptors staged in LDS, per-lane-group sources ----------------
     if (SLQ_RINGN_PRIO) __builtin_amdgcn_s_setprio(SLQ_RINGN_PRIO);
     unsigned char *stage = lds_raw + RG::kFlagBytes + (size_t)wave * (LAG * R * 256);
     auto stage_desc = [&](int k) {
@@ -223,62 +323,79 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + b * 64),
                                          (__attribute__((address_space(3))) void *)(stage + ((k % LAG) * R + b) * 256), 4, 0, 0);
     };
-    // descriptor k is requested LAG - 1 iterations before it is used, i.e. BEFORE the DMAs of tile k - LAG + 1: everything
-    // issued after it is then exactly what the counted wait below leaves outstanding
+    // The loader's iteration is the tile period of the alpha-only pass (scripts/ring_timeline.py, r03: 0.24 us counted wait +
+    // 0.23 us slot poll + 0.65 us for 12 DMAs = the pass's 1.0-1.2 us per tile; consumers idle half the time), so nothing in it
+    // waits for an LDS round trip any more: descriptor k + 1 and the `done` counter of tile k + 1's slot are READ right behind
+    // tile k's DMAs and waited for after the counted wait that follows - by then they are long there. (The loop is rotated -
+    // tile k's DMAs first, then everything that precedes tile k + 1's - so that the registers of the read-ahead are waited
+    // for in the iteration that loads them: a value carried over the back edge may be copied by the compiler at any time.)
+    // Order of a loader's requests: D0 D1 | D2 .. D_LAG T0 w0 D_LAG+1 T1 w1 D_LAG+2 T2 w2 ... (D_j: descriptor j, R requests; T_k:
+    // tile k's DMAs; w_k: the counted wait). w_k leaves outstanding exactly what was issued after D_k+2 - the DMAs of tiles
+    // k + 2 - LAG .. k and the LAG - 2 descriptors k + 3 .. k + LAG - so tile k + 1 - LAG has landed (it is published) and so has
+    // descriptor k + 2, which iteration k + 1 reads ahead.
+    auto desc_addr = [&](int k, int b) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + b) * 256) + lane * 4; };
+    int dcur[R], dv = 0, ab = 0;
+    stage_desc(0);
+    stage_desc(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < LAG - 1; ++i) stage_desc(i);
-    int hist[LAG - 1];  // DMAs issued for tiles k - 1, k - 2, ... (the ones that may still be in flight)
+    for (int b = 0; b < R; ++b) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dcur[b]) : "v"(desc_addr(0, b)) : "memory");
+#pragma unroll
+    for (int i = 2; i <= LAG; ++i) stage_desc(i);  // (descriptor LAG goes where descriptor 0 was: read just above)
+    int hist[LAG - 1];  // DMAs issued for tiles k, k - 1, ... (the ones that may still be in flight before tile k + 1)
 #pragma unroll
     for (int i = 0; i < LAG - 1; ++i) hist[i] = 0;
     bool ok = true;
-    for (int k = 0; k < ntiles + LAG && ok; ++k) {
 #ifdef SLQ_DEBUG_TIMES
-      // (scripts/ring_timeline.py: workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles)
-      unsigned long long *dbg = (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256) ? dbg_base + (size_t)k * 8 : nullptr;
-      if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+    // (scripts/ring_timeline.py: workgroup 0 of panel 0, loader 0 and consumer 0, the first 256 tiles)
+    auto dbg_of = [&](int k) -> unsigned long long * {
+      return (dbg_base && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && k < 256 && lane == 0) ? dbg_base + (size_t)k * 8 : nullptr;
+    };
+    if (auto *q = dbg_of(0)) q[0] = q[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-      stage_desc(k + LAG - 1);
-      // descriptor k is here and tile k - LAG has landed once only what was issued after descriptor k's request is outstanding:
-      // the DMAs of tiles k - LAG + 1 .. k - 1 and the R requests of each of the LAG - 1 descriptors since
-      int since = (LAG - 1) * R;
-#pragma unroll
-      for (int i = 0; i < LAG - 1; ++i) since += hist[i];
-      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
-      if (k >= LAG && lane == 0) bump(ready + (k - LAG) % NS);
-#ifdef SLQ_DEBUG_TIMES
-      if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
-#endif
+    for (int k = 0; k < ntiles + LAG - 1 && ok; ++k) {
       int issued = 0;
       if (k < ntiles) {
         const int slot = k % NS;
-        int dreg[R];
-#pragma unroll
-        for (int b = 0; b < R; ++b)
-          asm volatile("ds_read_b32 %0, %1" : "=&v"(dreg[b]) : "v"((unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + b) * 256) + lane * 4) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (k >= NS) ok = spin(done + slot, NC * (k / NS));  // the slot's previous tile has been consumed
+        if (k >= NS) {  // the slot's previous tile has been consumed? (usually known from the read-ahead; else poll)
+          if (__builtin_amdgcn_readfirstlane(ab)) ok = false;
+          else if (__builtin_amdgcn_readfirstlane(dv) < NC * (k / NS)) ok = spin(done + slot, NC * (k / NS));
+        }
 #ifdef SLQ_DEBUG_TIMES
-        if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
+        if (auto *q = dbg_of(k)) q[2] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (ok) {
           unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
-          const int D = lane_bcast(dreg[0], kDescCols);
+          const int D = lane_bcast(dcur[0], kDescCols);
           const int nd = (D + R - 1) / R;
-          for (int d = wave; d < nd; d += RG::kLoaders) {
-            // lane group b lands line d * R + b (block b of the descriptor); past the tile's last line the descriptor repeats
-            // that line: it lands once more, in a line nobody reads (a lane's destination is fixed by its number)
-            int col = lane_bcast(dreg[0], kDescList + d);
+          // lane group b lands line d * R + b (block b of the descriptor); past the tile's last line the descriptor repeats
+          // that line: it lands once more, in a line nobody reads (a lane's destination is fixed by its number)
+          auto line_col = [&](int d) {
+            int col = lane_bcast(dcur[0], kDescList + d);
 #pragma unroll
             for (int b = 1; b < R; ++b) {
-              const int cb = lane_bcast(dreg[b], kDescList + d);
+              const int cb = lane_bcast(dcur[b], kDescList + d);
               col = g == b ? cb : col;
             }
+            return col;
+          };
+          auto land = [&](int col, int d) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)col * PW),
                                              (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
+          };
+          int d = wave;
+          for (; d + RG::kLoaders < nd; d += 2 * RG::kLoaders) {  // two lines per turn: two independent address chains
+            const int c0 = line_col(d), c1 = line_col(d + RG::kLoaders);
+            land(c0, d);
+            land(c1, d + RG::kLoaders);
+            issued += 2;
+          }
+          if (d < nd) {
+            land(line_col(d), d);
             ++issued;
           }
-          const int chunks = lane_bcast(dreg[0], kDescRecChunks);
-          const char *rsrc = tile_rec + (int64_t)lane_bcast(dreg[0], kDescRecOff) * 16 + lane * 16;
+          const int chunks = lane_bcast(dcur[0], kDescRecChunks);
+          const char *rsrc = tile_rec + (int64_t)lane_bcast(dcur[0], kDescRecOff) * 16 + lane * 16;
           for (int c = wave; c < chunks; c += RG::kLoaders) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
                                              (__attribute__((address_space(3))) void *)(img + RG::kLines * 1024 + c * 1024), 16, 0, 0);
@@ -287,14 +404,46 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         }
       }
 #ifdef SLQ_DEBUG_TIMES
-      if (dbg && lane == 0) {
-        dbg[3] = __builtin_amdgcn_s_memrealtime();
-        dbg[7] = (unsigned long long)issued;
+      if (auto *q = dbg_of(k)) {
+        q[3] = __builtin_amdgcn_s_memrealtime();
+        q[7] = (unsigned long long)issued;
       }
+      if (auto *q = dbg_of(k + 1)) q[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+      // ---- what precedes tile k + 1 ----
+      // read ahead: descriptor k + 1 (landed: w_k-1, or the prologue's wait), its slot's counter, the abort flag
+      int dnew[R], dvn, abn;
+      {
+        const unsigned da = (unsigned)(uintptr_t)(done + (k + 1) % NS), aa = (unsigned)(uintptr_t)abort_f;
+        if constexpr (R == 1)
+          asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5" : "=&v"(dnew[0]), "=&v"(dvn), "=&v"(abn) : "v"(desc_addr(k + 1, 0)), "v"(da), "v"(aa) : "memory");
+        else if constexpr (R == 2)
+          asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7"
+                       : "=&v"(dnew[0]), "=&v"(dnew[1]), "=&v"(dvn), "=&v"(abn) : "v"(desc_addr(k + 1, 0)), "v"(desc_addr(k + 1, 1)), "v"(da), "v"(aa) : "memory");
+        else
+          asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8\n\tds_read_b32 %3, %9\n\tds_read_b32 %4, %10\n\tds_read_b32 %5, %11"
+                       : "=&v"(dnew[0]), "=&v"(dnew[1]), "=&v"(dnew[2]), "=&v"(dnew[3]), "=&v"(dvn), "=&v"(abn)
+                       : "v"(desc_addr(k + 1, 0)), "v"(desc_addr(k + 1, 1)), "v"(desc_addr(k + 1, 2)), "v"(desc_addr(k + 1, 3)), "v"(da), "v"(aa) : "memory");
+      }
 #pragma unroll
       for (int i = LAG - 2; i > 0; --i) hist[i] = hist[i - 1];
       hist[0] = issued;
+      int since = (LAG - 2) * R;
+#pragma unroll
+      for (int i = 0; i < LAG - 1; ++i) since += hist[i];
+      wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
+      if (k + 1 >= LAG && lane == 0) bump(ready + (k + 1 - LAG) % NS);
+      if constexpr (R == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dvn), "+v"(abn)::"memory");
+      else if constexpr (R == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dnew[1]), "+v"(dvn), "+v"(abn)::"memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dnew[1]), "+v"(dnew[2]), "+v"(dnew[3]), "+v"(dvn), "+v"(abn)::"memory");
+#pragma unroll
+      for (int b = 0; b < R; ++b) dcur[b] = dnew[b];
+      dv = dvn;
+      ab = abn;
+      stage_desc(k + 1 + LAG);  // (into descriptor k + 1's place: read and waited for just above)
+#ifdef SLQ_DEBUG_TIMES
+      if (auto *q = dbg_of(k + 1)) q[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------
@@ -426,6 +575,113 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         }
       }
     };
+    // The alpha-only pass has nothing but this to do per tile, and a row is a chain of three LDS round trips (record header ->
+    // its entries -> their image lines): with the loaders no longer in the way (r03: four of them land a 5-point grid's upper
+    // tiles in 0.35 ms) the consumers' chains were the pass's 0.54 ms. Here a wave walks ALL its rows of the tile together -
+    // every row's entries requested before any is used, then every row's lines - so a tile costs three round trips, not 3 MR.
+    auto do_alpha_joint = [&](const unsigned char *img, int nrows, const VF *xp_in) {
+      const unsigned char *rec = img + RG::kLines * 1024;
+      const F *xl = (const F *)img + cl * V;
+      const int head = ((const int *)rec)[lane & 31];
+      const int valoff = lane_bcast(head, RG::kRecValOffW);
+      int p0[MR], p1[MR], si[MR], lcv[MR];
+      F vav[MR];
+      VF xc[MR];
+      bool live[MR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int lr = cw + i * NC;
+        live[i] = lr < nrows;
+        const int lrc = live[i] ? lr : 0;  // (a row group past the tile's end walks no entries and adds nothing)
+        p0[i] = lane_bcast(head, lrc);
+        p1[i] = live[i] ? lane_bcast(head, lrc + 1) : p0[i];
+        si[i] = lane_bcast(head, RG::kRecSelfW + lrc);
+        const int e = max(min(p0[i] + (lane & (kChunk - 1)), p1[i] - 1), 0);
+        lcv[i] = *(const int *)(rec + RG::kRecHeadB + e * 4);
+        vav[i] = *(const F *)(rec + valoff + e * (int)sizeof(F));
+        xc[i] = *(const VF *)(xl + (size_t)si[i] * PW);
+      }
+      VF x[MR][kChunk];
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) x[i][q] = *(const VF *)(xl + (size_t)(q < p1[i] - p0[i] ? lane_bcast(lcv[i], q) : si[i]) * PW);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int cnt0 = p1[i] - p0[i];
+        VF acc = (VF)(F)0;
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) acc += (q < cnt0 ? lane_bcast(vav[i], q) : (F)0) * x[i][q];
+        for (int pb = p0[i] + kChunk; pb < p1[i]; pb += kChunk) {  // rows of more than kChunk entries: the rest as do_group walks them
+          const int cnt = p1[i] - pb;
+          const int e = min(pb + (lane & (kChunk - 1)), p1[i] - 1);
+          const int lcw = *(const int *)(rec + RG::kRecHeadB + e * 4);
+          const F vaw = *(const F *)(rec + valoff + e * (int)sizeof(F));
+          VF y[kChunk];
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) y[q] = *(const VF *)(xl + (size_t)(q < cnt ? lane_bcast(lcw, q) : si[i]) * PW);
+#pragma unroll
+          for (int q = 0; q < kChunk; ++q) acc += (q < cnt ? lane_bcast(vaw, q) : (F)0) * y[q];
+        }
+        if (live[i]) {
+          VF w = sc * acc;
+          if (!first) w -= cp * xp_in[i];
+          acc1 += (sc * xc[i]) * w;
+        }
+      }
+    };
+    // ... and on a stream with padded rows (the upper-triangle stream of whole-row panels) nothing per entry is conditional and
+    // nothing goes through v_readlane: a row's four line numbers and four coefficients are aligned 16-/32-byte LDS reads that every
+    // lane makes for itself (one address: a broadcast), a line's address is one VALU add, an entry two FMAs. ~80 instructions per
+    // tile and wave instead of ~350 with a branch per entry - the consumers, not the memory system, were this pass's limit.
+    auto do_alpha_padded = [&](const unsigned char *img, int nrows, const VF *xp_in) {
+      using I4 = int __attribute__((ext_vector_type(4)));
+      typedef F F4 __attribute__((ext_vector_type(4), aligned(16)));  // (four doubles: two 16-byte reads)
+      const unsigned char *rec = img + RG::kLines * 1024;
+      const F *xl = (const F *)img + cl * V;
+      const int *rw = (const int *)rec;
+      const int valoff = rw[RG::kRecValOffW];
+      int p0[MR], p1[MR], si[MR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int lr = cw + i * NC;  // (past the tile's last row: zeros of the header, i.e. row 0's first chunk - computed, not added)
+        p0[i] = rw[lr];
+        p1[i] = rw[lr + 1];
+        si[i] = rw[RG::kRecSelfW + lr];
+      }
+      I4 lc[MR];
+      F4 va[MR];
+      VF xc[MR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        lc[i] = *(const I4 *)(rec + RG::kRecHeadB + p0[i] * 4);
+        va[i] = *(const F4 *)(rec + valoff + p0[i] * (int)sizeof(F));
+        xc[i] = *(const VF *)(xl + (size_t)si[i] * PW);
+      }
+      VF x[MR][4];
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[i][q] = *(const VF *)(xl + (size_t)lc[i][q] * PW);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        VF acc = va[i][0] * x[i][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) acc += va[i][q] * x[i][q];
+        const int last = __builtin_amdgcn_readfirstlane(p1[i]);
+        for (int pb = __builtin_amdgcn_readfirstlane(p0[i]) + 4; pb < last; pb += 4) {  // rows of more than four entries
+          const I4 lw = *(const I4 *)(rec + RG::kRecHeadB + pb * 4);
+          const F4 vw = *(const F4 *)(rec + valoff + pb * (int)sizeof(F));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc += vw[q] * *(const VF *)(xl + (size_t)lw[q] * PW);
+        }
+        if (cw + i * NC < nrows) {
+          VF w = sc * acc;
+          if (!first) w -= cp * xp_in[i];
+          acc1 += (sc * xc[i]) * w;
+        }
+      }
+    };
     int dcur = load_desc(grp), dnext = load_desc(grp + G);
     {
       const int r_lo0 = lane_bcast(dcur, kDescRow0), nrows0 = lane_bcast(dcur, kDescRows);
@@ -461,10 +717,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
 #ifdef SLQ_DEBUG_TIMES
         if (dbg && lane == 0) dbg[5] = __builtin_amdgcn_s_memrealtime();
 #endif
+        if constexpr (PASS == PASS_ALPHA && R == 1) {
+          if (padded_rows) do_alpha_padded(img, nrows, xpc);
+          else do_alpha_joint(img, nrows, xpc);
+        } else {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-          if ((cw + i * NC) * R >= nrows) break;
-          do_group(img, i, r_lo, nrows, xpc[i], uc[i]);
+          for (int i = 0; i < MR; ++i) {
+            if ((cw + i * NC) * R >= nrows) break;
+            do_group(img, i, r_lo, nrows, xpc[i], uc[i]);
+          }
         }
       } else {
 #ifdef SLQ_DEBUG_TIMES

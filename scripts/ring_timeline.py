@@ -49,8 +49,10 @@ for k in list(range(0, 12)) + list(range(100, 112)):
 		print(f"{k:5d} {T[k,0]:8.2f} {T[k,1]:10.2f} {T[k,2]:12.2f} {T[k,3]:9.2f} | {T[k,4]:7.2f} {T[k,5]:8.2f} {T[k,6]:9.2f} | {int(buf[k,7])}")
 S = T[16:]
 print("loader per tile (us): counted wait %.2f, slot wait %.2f, issue %.2f" % ((S[:, 1] - S[:, 0]).mean(), (S[:, 2] - S[:, 1]).mean(), (S[:, 3] - S[:, 2]).mean()))
-print("consumer per tile (us): prefetch+loop top %.2f (prev release -> poll), poll %.2f, compute %.2f" % ((S[1:, 4] - S[:-1, 6]).mean(), (S[:, 5] - S[:, 4]).mean(), (S[:, 6] - S[:, 5]).mean()))
+Cs = S[(np.arange(len(S)) + 16) % 2 == 0]  # consumer 0 belongs to group 0: it stamps the even tiles only (16 waves: two groups)
+print("consumer 0, per tile OF ITS GROUP (us): loop top %.2f (prev release -> poll), poll %.2f, compute %.2f; group period %.2f" % (
+	(Cs[1:, 4] - Cs[:-1, 6]).mean(), (Cs[:, 5] - Cs[:, 4]).mean(), (Cs[:, 6] - Cs[:, 5]).mean(), np.diff(Cs[:, 4]).mean()))
 lag = 2
 land = S[lag:, 1] - S[:-lag, 3]
 print("issue end of tile k -> seen landed (at the loader's next-but-one iteration): %.2f us mean, %.2f min" % (land.mean(), land.min()))
-print("published -> consumer sees it: %.2f us" % (S[:-lag, 5] - S[lag:, 1]).mean())
+print("published -> consumer sees it: %.2f us (even tiles)" % (S[:-lag, 5] - S[lag:, 1])[(np.arange(len(S) - lag) + 16) % 2 == 0].mean())
