@@ -117,6 +117,7 @@ struct slq_operator {
   // narrow panels (slq_ring.hpp): R = 2, 4 consecutive tiles merged into one, built the first time a plan asks for them
   // (ensure_ring_stream); [0] R = 2, [1] R = 4; *_u over the upper triangle where the operator has that stream
   struct MergedStream {
+    bool u_padded = false;  // the upper stream's rows are padded to whole chunks (build_ring_stream: pad_rows)
     int32_t *desc = nullptr, *desc_u = nullptr;
     char *rec = nullptr, *rec_u = nullptr;
     int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -222,6 +223,7 @@ struct slq_plan {
   bool gram;                  // steps with 1..8 ring columns take their projections from Gram rows of the update passes (SLQ_GRAM)
   const int32_t *rs_desc, *rs_desc_u;  // the stream the plan's ring-fed passes read (full rows / upper triangle or null)
   const char *rs_rec, *rs_rec_u;
+  bool rs_u_padded;            // ... whose rows are padded to whole chunks of four entries (the alpha-only pass's branch-free consumer)
   int32_t rs_xcd[9];
   bool ring_staged;           // the alpha-only pass's loaders go through registers (SLQ_RING_STAGED; slq_ring.hpp: GEO 1)
 };
@@ -774,11 +776,11 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
   const size_t dw = (size_t)64 * R, head_bytes = (size_t)kRecHeadBytes * R;
   const int valoff_w = 16 * R - 1, self_w = 16 * R;
   desc.alloc(ntiles * dw);  // (zeroed tile by tile below, by the thread that fills the tile)
-  // *pad_rows (R = 1, the alpha-only pass's stream): every row's entries padded to a multiple of four, at least four, with
+  // *pad_rows (the alpha-only pass's upper-triangle streams): every row's entries padded to a multiple of four, at least four, with
   // {the row's own line, 0} - its consumer then reads a row's entries four at a time with aligned 16-byte LDS reads and
   // without a single per-entry condition (slq_ring.hpp: do_alpha_padded). Given up (*pad_rows = false) if some tile's record
   // would outgrow its slot.
-  bool pad = pad_rows && *pad_rows && R == 1;
+  bool pad = pad_rows && *pad_rows;
   auto padded = [](int32_t cnt) { return std::max<int32_t>(4, (cnt + 3) / 4 * 4); };
   if (pad) {
     for (size_t t = 0; t < ntiles && pad; ++t) {
@@ -1631,7 +1633,7 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
     }
     m.xcd_tile[8] = (int32_t)mrow.size();
     mrow.push_back((int32_t)n);
-    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines) -> bool {
+    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines, bool *pad) -> bool {
       std::vector<int32_t> tp, tc, lc, si;
       RawBuf<int32_t> desc;
       RawBuf<char> rec;
@@ -1639,22 +1641,24 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
       build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
       *max_lines = mx;
       if (mx > kRingTileCols * R) return false;  // (cannot happen: a union of R lists of <= 36)
-      if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec);
-      else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec);
+      if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
+      else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
       if (hipMalloc((void **)desc_d, desc.size() * 4) != hipSuccess) return false;
       if (hipMalloc((void **)rec_d, rec.size()) != hipSuccess) return false;
       return hipMemcpy(*desc_d, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(*rec_d, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
     };
-    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec, &m.max_lines);
+    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec, &m.max_lines, nullptr);
     if (ok && op->tile_desc_u && op->rowptr_u) {
       const size_t nu = (size_t)op->nnz_u;
+      bool upad = env_int("SLQ_RING_PAD_ROWS", 1) != 0;
       std::vector<int32_t> urp((size_t)n + 1), uci(nu);
       std::vector<char> uva(nu * es);
       ok = hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess &&
            hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) == hipSuccess &&
            hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) == hipSuccess &&
-           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u, &m.max_lines_u);
+           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u, &m.max_lines_u, &upad);
+      m.u_padded = ok && upad;
     }
     if (!ok) {
       for (void **q : {(void **)&m.desc, (void **)&m.rec, (void **)&m.desc_u, (void **)&m.rec_u}) {
@@ -1948,6 +1952,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     p->ring_gen = p->ring_deep = p->gram = false;
     p->rs_desc = p->rs_desc_u = nullptr;
     p->rs_rec = p->rs_rec_u = nullptr;
+    p->rs_u_padded = false;
     p->ring_staged = false;
     for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x];
     if (op->kind == OP_CSR && op->tiles.tile_ptr && p->sw.tiles) {
@@ -1956,7 +1961,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         if (op->tiles_ringed) {
           p->rs_desc = op->tile_desc, p->rs_rec = op->tile_rec;
           if (op->tile_desc_u && op->upper_per_row <= (double)env_int("SLQ_RING_ALPHA_MAX_X100", (int)(100 * kTileAlphaColsPerRow)) / 100.0)
-            p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u;
+            p->rs_desc_u = op->tile_desc_u, p->rs_rec_u = op->tile_rec_u, p->rs_u_padded = op->tile_u_padded;
           p->ring_gen = p->sw.nt && env_int("SLQ_RING_GEN", 1) != 0;
           p->ring_deep = p->sw.nt && env_int("SLQ_RING_DEEP", 1) != 0;
         }
@@ -1966,7 +1971,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->ringR = 64 / p->LPR;
         p->ring_gen = true;
         p->ring_deep = env_int("SLQ_RING_DEEP", 1) != 0;
-        p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u;
+        p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u, p->rs_u_padded = m.u_padded;
         for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
       }
       // alpha-only pass: loaders through registers on the merged tiles of narrow panels (measured: 100^3, 64 probes 0.255 -> 0.221 ms,
@@ -2695,7 +2700,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.gamma = p->st.gamma;
   a.part = p->part;
   a.bpad = p->bpad;
-  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0) | ((upper && p->ringR == 1 && p->op->tile_u_padded) ? 8 : 0);  // bit 3: padded rows
+  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0) | ((upper && p->rs_u_padded) ? 8 : 0);  // bit 3: padded rows
   a.fail = p->ring_fail_d;
   a.dbg = pass == env_int("SLQ_DEBUG_PASS", PASS_ADOTS) ? debug_times_buffer() : nullptr;  // (diagnostic builds: the pass whose time line is stamped)
   const bool d = p->dtype == SLQ_F64;

@@ -21,6 +21,8 @@
 // order, rows -> waves and the final reduction over waves static. Results are reproducible bit for bit and equal to
 // the other launch sequences' up to the order of the cross-row sums.
 #pragma once
+#include <type_traits>
+
 #include "slq_common.hpp"
 
 namespace slq {
@@ -630,10 +632,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         }
       }
     };
-    // ... and on a stream with padded rows (the upper-triangle stream of whole-row panels) nothing per entry is conditional and
-    // nothing goes through v_readlane: a row's four line numbers and four coefficients are aligned 16-/32-byte LDS reads that every
-    // lane makes for itself (one address: a broadcast), a line's address is one VALU add, an entry two FMAs. ~80 instructions per
-    // tile and wave instead of ~350 with a branch per entry - the consumers, not the memory system, were this pass's limit.
+    // ... and on a stream with padded rows (the upper-triangle streams; slq.hip: build_ring_stream) nothing per entry is conditional
+    // and nothing goes through v_readlane: a row's four line numbers and four coefficients are aligned 16-/32-byte LDS reads that
+    // every lane makes for itself (the lanes of a row read one address: a broadcast), a line's address is one VALU add, an entry
+    // two FMAs. ~80 instructions per tile and wave instead of ~350 with a branch per entry - the consumers' instruction stream,
+    // not the memory system, was this pass's limit. Row groups are walked two at a time (registers: 16 waves leave 128 each).
     auto do_alpha_padded = [&](const unsigned char *img, int nrows, const VF *xp_in) {
       using I4 = int __attribute__((ext_vector_type(4)));
       typedef F F4 __attribute__((ext_vector_type(4), aligned(16)));  // (four doubles: two 16-byte reads)
@@ -641,45 +644,60 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       const F *xl = (const F *)img + cl * V;
       const int *rw = (const int *)rec;
       const int valoff = rw[RG::kRecValOffW];
-      int p0[MR], p1[MR], si[MR];
+      auto batch = [&](auto i0_c, auto cnt_c) {
+        constexpr int I0 = decltype(i0_c)::value, CNT = decltype(cnt_c)::value;
+        int p0[CNT], p1[CNT], si[CNT];
+        bool live[CNT];
 #pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        const int lr = cw + i * NC;  // (past the tile's last row: zeros of the header, i.e. row 0's first chunk - computed, not added)
-        p0[i] = rw[lr];
-        p1[i] = rw[lr + 1];
-        si[i] = rw[RG::kRecSelfW + lr];
-      }
-      I4 lc[MR];
-      F4 va[MR];
-      VF xc[MR];
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        lc[i] = *(const I4 *)(rec + RG::kRecHeadB + p0[i] * 4);
-        va[i] = *(const F4 *)(rec + valoff + p0[i] * (int)sizeof(F));
-        xc[i] = *(const VF *)(xl + (size_t)si[i] * PW);
-      }
-      VF x[MR][4];
-#pragma unroll
-      for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[i][q] = *(const VF *)(xl + (size_t)lc[i][q] * PW);
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        VF acc = va[i][0] * x[i][0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) acc += va[i][q] * x[i][q];
-        const int last = __builtin_amdgcn_readfirstlane(p1[i]);
-        for (int pb = __builtin_amdgcn_readfirstlane(p0[i]) + 4; pb < last; pb += 4) {  // rows of more than four entries
-          const I4 lw = *(const I4 *)(rec + RG::kRecHeadB + pb * 4);
-          const F4 vw = *(const F4 *)(rec + valoff + pb * (int)sizeof(F));
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc += vw[q] * *(const VF *)(xl + (size_t)lw[q] * PW);
+        for (int i = 0; i < CNT; ++i) {
+          const int lr = (cw + (I0 + i) * NC) * R + g;
+          live[i] = lr < nrows;
+          const int lrc = live[i] ? lr : 0;  // (a lane past the tile's last row walks row 0's first chunk and adds nothing)
+          p0[i] = rw[lrc];
+          p1[i] = live[i] ? rw[lrc + 1] : 0;
+          si[i] = rw[RG::kRecSelfW + lrc];
         }
-        if (cw + i * NC < nrows) {
-          VF w = sc * acc;
-          if (!first) w -= cp * xp_in[i];
-          acc1 += (sc * xc[i]) * w;
+        I4 lc[CNT];
+        F4 va[CNT];
+        VF xc[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+          lc[i] = *(const I4 *)(rec + RG::kRecHeadB + p0[i] * 4);
+          va[i] = *(const F4 *)(rec + valoff + p0[i] * (int)sizeof(F));
+          xc[i] = *(const VF *)(xl + (size_t)si[i] * PW);
         }
+        VF x[CNT][4];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[i][q] = *(const VF *)(xl + (size_t)lc[i][q] * PW);
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+          VF acc = va[i][0] * x[i][0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) acc += va[i][q] * x[i][q];
+          // rows of more than four entries (R > 1: as long as some lane group's row has more; the others add zeros)
+          for (int pb = p0[i] + 4; __builtin_amdgcn_ballot_w64(pb < p1[i]) != 0; pb += 4) {
+            const bool on = pb < p1[i];
+            const int pc = on ? pb : p0[i];
+            const I4 lw = *(const I4 *)(rec + RG::kRecHeadB + pc * 4);
+            const F4 vw = *(const F4 *)(rec + valoff + pc * (int)sizeof(F));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += (on ? vw[q] : (F)0) * *(const VF *)(xl + (size_t)lw[q] * PW);
+          }
+          if (live[i]) {
+            VF w = sc * acc;
+            if (!first) w -= cp * xp_in[I0 + i];
+            acc1 += (sc * xc[i]) * w;
+          }
+        }
+      };
+      if constexpr (MR == 1) batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+      else {
+        batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        if constexpr (MR == 3) batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+        else if constexpr (MR >= 4) batch(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        static_assert(MR <= 4, "row groups of a tile per consumer wave");
       }
     };
     int dcur = load_desc(grp), dnext = load_desc(grp + G);
@@ -720,6 +738,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
         if constexpr (PASS == PASS_ALPHA && R == 1) {
           if (padded_rows) do_alpha_padded(img, nrows, xpc);
           else do_alpha_joint(img, nrows, xpc);
+        } else if (PASS == PASS_ALPHA && padded_rows) {
+          do_alpha_padded(img, nrows, xpc);
         } else {
 #pragma unroll
           for (int i = 0; i < MR; ++i) {
