@@ -862,6 +862,39 @@ def test_ring_fed_passes_every_panel_width_and_ring_depth(oracle, eng, monkeypat
 	op.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"SLQ_RING_PAD_ROWS": "0"}, {"SLQ_SYM_ALPHA": "0"}])
+def test_alpha_pass_stream_forms(oracle, eng, monkeypatch, env):
+	"""The alpha-only ring pass (q_c^T A q_c, src/primate/include/lanczos.h:127-129) on its three streams: the upper triangle
+	with rows padded to whole chunks of four entries (the branch-free consumer, default), the same stream unpadded
+	(SLQ_RING_PAD_ROWS=0), the full rows (SLQ_SYM_ALPHA=0: what a non-symmetric pattern gets) - wide, 64- and 20-probe panels,
+	orth 0 (alpha + update) and 3 (Gram sequence), on a 5-point grid (3 upper entries per row: one padded chunk) and on a band
+	with gaps whose rows hold 1..6 upper entries (one or two chunks, differing between the rows a wave walks together)."""
+	rng = np.random.default_rng(77)
+	monkeypatch.setenv("SLQ_TILES", "2")
+	for k, v in env.items():
+		monkeypatch.setenv(k, v)
+	n = 20011
+	offs = [1, 2, 3, 4, 5]
+	D = [rng.uniform(0.2, 1.0, n - o) * (rng.random(n - o) > 0.25) for o in offs]
+	B = sp.diags(D, offs, shape=(n, n))
+	band = (B + B.T + sp.diags(np.full(n, 12.0))).tocsr()
+	band.eliminate_zeros()
+	band.sort_indices()
+	for name, A in (("lap2d", laplacian_2d(150)), ("band", band)):
+		op = eng.DeviceOperator(A)
+		for P in (130, 64, 20):
+			X = np.asfortranarray(np.floor(rng.random((A.shape[0], P)) * 2) * 2 - 1)
+			cols = [0, P // 2, P - 1]
+			plan = eng.LanczosPlan(op, P, 12, 3)
+			info = plan.describe()
+			plan.close()
+			assert info["tiles"] == 2, info
+			for o in (0, 3):
+				ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, o, fun="log", fresh_q=True)
+				np.testing.assert_allclose(eng.quad_batch(op, X, 12, o, fun="log")[cols], ref, rtol=1e-10, err_msg=f"{name} {env} P={P} orth={o}")
+		op.close()
+
+
 def test_tall_skinny_mfma_products(eng):
 	"""slq_dmat_gemm_tn / _nn (fp64 MFMA) against NumPy, ragged sizes on every edge."""
 	rng = np.random.default_rng(0)
