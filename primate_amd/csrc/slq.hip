@@ -1847,7 +1847,7 @@ static int plan_bytes_on(const slq_operator *op, int nprobes, int deg, int orth,
   choose_geometry(op->dtype, nprobes, &LPR, &PW, &NP);
   const size_t panel = (size_t)NP * PW * esize(op->dtype);
   if (op->kind != OP_CSR) {
-    const bool big_tiles = op->kind == OP_DENSE && op->dtype == SLQ_F64 && PW >= 32;
+    const bool big_tiles = op->kind == OP_DENSE && (op->dtype == SLQ_F32 || PW >= 32);  // K-split slabs of the MFMA dense kernels (<= 16)
     *bytes += (size_t)(1 + (big_tiles ? 16 : 0)) * panel * (size_t)op->n;
   }
   if (op->kind == OP_GRAM) *bytes += panel * (size_t)op->mrows;

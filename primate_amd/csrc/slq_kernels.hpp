@@ -1260,6 +1260,10 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_tile(int n, const double 
 // interleaved row (column) tiles; with k-strides of 1 KiB / 512 B every 16-lane group of a ds_read_b128 hits 64 distinct banks.
 // Requires lda even (16-byte aligned row pairs); slq.hip falls back to k_dense_mfma_tile otherwise.
 constexpr int kDenseBK = 16;
+#ifndef SLQ_DENSE_DEPTH
+#define SLQ_DENSE_DEPTH 4
+#endif
+constexpr int kDenseDepth = SLQ_DENSE_DEPTH;  // stages of operands in registers ahead of the one in LDS (k_dense_mfma_lds, k_dense_mfma32_lds)
 template <int NCG>
 __global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *__restrict__ A, int64_t lda, const double *__restrict__ X, int ldw,
                                                            int col0, double *__restrict__ raw, int64_t raw_stride) {
@@ -1288,8 +1292,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *
   const int perz = (kq_all + ks - 1) / ks;
   const int k_begin = min(n, kz * perz * 4), k_end = min(n, k_begin + perz * 4);
   const int nstage = (k_end - k_begin + BK - 1) / BK;
-  d2u_t ra[APT], rx[XPT];
-  auto fetch = [&](int st) {
+  // kDenseDepth register sets hold the stages st + 1 .. st + kDenseDepth while stage st's MFMAs run out of LDS: a stage is
+  // 0.4 us of MFMAs, a load from the Infinity Cache or HBM 1-2 us away (one set, r03 first form: every stage waited for its
+  // successor's loads - 87 us per 5000^2 x 64 product). A set is 12 VGPRs.
+  constexpr int D = kDenseDepth;
+  d2u_t ra[D][APT], rx[D][XPT];
+  auto fetch = [&](int st, d2u_t (&fa)[APT], d2u_t (&fx)[XPT]) {
     const int k0 = k_begin + st * BK;
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
@@ -1301,7 +1309,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *
         if (row + 1 < n) v = *(const d2u_t *)ap;
         else if (row < n) v[0] = ap[0];
       }
-      ra[i] = v;
+      fa[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
@@ -1309,41 +1317,49 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma_lds(int n, const double *
       const int k = k0 + kk;
       d2u_t v = (d2u_t)0.0;
       if (pc < BK * BN / 2 && k < k_end) v = *(const d2u_t *)(xp + (int64_t)k * PW + 2 * cp);
-      rx[i] = v;
+      fx[i] = v;
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const d2u_t (&fa)[APT], const d2u_t (&fx)[XPT]) {
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 2), rp = pc % (BM / 2);
-      *(d2u_t *)&As[buf][kk][2 * rp] = ra[i];
+      *(d2u_t *)&As[buf][kk][2 * rp] = fa[i];
     }
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int pc = threadIdx.x + i * kBlock, kk = pc / (BN / 2), cp = pc % (BN / 2);
-      if (pc < BK * BN / 2) *(d2u_t *)&Xs[buf][kk][2 * cp] = rx[i];
+      if (pc < BK * BN / 2) *(d2u_t *)&Xs[buf][kk][2 * cp] = fx[i];
     }
   };
-  if (nstage > 0) {
-    fetch(0);
-    stash(0);
-  }
+  // set (s % D) holds stage s; stage 0 goes straight into LDS, sets 1 .. D - 1 and then 0 are loaded (stages past the end: zeros)
+  fetch(0, ra[0], rx[0]);
+  stash(0, ra[0], rx[0]);
+#pragma unroll
+  for (int d = 1; d < D; ++d) fetch(d, ra[d], rx[d]);
   __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstage) fetch(st + 1);  // in flight while this stage's MFMAs run
+  for (int st0 = 0; st0 < nstage; st0 += D) {
 #pragma unroll
-    for (int q = 0; q < BK / 4; ++q) {
-      const d2u_t a = *(const d2u_t *)&As[buf][q * 4 + lk][rg * 32 + 2 * lr];
-      const d2u_t b = *(const d2u_t *)&Xs[buf][q * 4 + lk][cg * 32 + 2 * lr];
+    for (int i = 0; i < D; ++i) {
+      const int st = st0 + i;
+      if (st < nstage) {  // (uniform)
+        const int buf = st & 1;
+        fetch(st + D, ra[i], rx[i]);  // the set stage st came from is free: D stages ahead
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        acc[0][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[h], acc[0][h], 0, 0, 0);
-        acc[1][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[h], acc[1][h], 0, 0, 0);
+        for (int q = 0; q < BK / 4; ++q) {
+          const d2u_t a = *(const d2u_t *)&As[buf][q * 4 + lk][rg * 32 + 2 * lr];
+          const d2u_t b = *(const d2u_t *)&Xs[buf][q * 4 + lk][cg * 32 + 2 * lr];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            acc[0][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[h], acc[0][h], 0, 0, 0);
+            acc[1][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[h], acc[1][h], 0, 0, 0);
+          }
+        }
+        // stage st + 1 into the other buffer (last read in stage st - 1: every wave is past the barrier that ended it)
+        if (st + 1 < nstage) stash(buf ^ 1, ra[(i + 1) % D], rx[(i + 1) % D]);
+        __syncthreads();
       }
     }
-    if (st + 1 < nstage) stash(buf ^ 1);  // (that buffer was last read in stage st - 1: every wave is past the barrier that ended it)
-    __syncthreads();
   }
   double *out = raw + (int64_t)kz * raw_stride + poff;
   const int rb = rbase + rg * 32, cbase = col0 + 32 * cg;
@@ -1398,8 +1414,9 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma32_lds(int n, const float 
   const int perz = (kq_all + ks - 1) / ks;
   const int k_begin = min(n, kz * perz * 4), k_end = min(n, k_begin + perz * 4);
   const int nstage = (k_end - k_begin + BK - 1) / BK;
-  f4v_t ra[APT], rx;
-  auto fetch = [&](int st) {
+  constexpr int D = kDenseDepth;  // register sets ahead of the stage in LDS, as in k_dense_mfma_lds (12 VGPRs each)
+  f4v_t ra[D][APT], rx[D];
+  auto fetch = [&](int st, f4v_t (&fa)[APT], f4v_t &fx) {
     const int k0 = k_begin + st * BK;
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
@@ -1415,44 +1432,50 @@ __global__ __launch_bounds__(kBlock) void k_dense_mfma32_lds(int n, const float 
             if (row + e < n) v[e] = ap[e];
         }
       }
-      ra[i] = v;
+      fa[i] = v;
     }
     {
       const int pc = threadIdx.x, kk = pc / (BN / 4), c4 = pc % (BN / 4);
       const int k = k0 + kk;
-      rx = (f4v_t)0.0f;
-      if (pc < BK * BN / 4 && k < k_end && 4 * c4 < ncols) rx = *(const f4v_t *)(xp + (int64_t)k * PW + 4 * c4);
+      fx = (f4v_t)0.0f;
+      if (pc < BK * BN / 4 && k < k_end && 4 * c4 < ncols) fx = *(const f4v_t *)(xp + (int64_t)k * PW + 4 * c4);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const f4v_t (&fa)[APT], const f4v_t &fx) {
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int pc = threadIdx.x + i * kBlock, kk = pc / (BM / 4), r4 = pc % (BM / 4);
-      *(f4v_t *)&As[buf][kk][4 * r4] = ra[i];
+      *(f4v_t *)&As[buf][kk][4 * r4] = fa[i];
     }
     const int pc = threadIdx.x, kk = pc / (BN / 4), c4 = pc % (BN / 4);
-    if (pc < BK * BN / 4) *(f4v_t *)&Xs[buf][kk][4 * c4] = rx;
+    if (pc < BK * BN / 4) *(f4v_t *)&Xs[buf][kk][4 * c4] = fx;
   };
-  if (nstage > 0) {
-    fetch(0);
-    stash(0);
-  }
+  fetch(0, ra[0], rx[0]);
+  stash(0, ra[0], rx[0]);
+#pragma unroll
+  for (int d = 1; d < D; ++d) fetch(d, ra[d], rx[d]);
   __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstage) fetch(st + 1);
+  for (int st0 = 0; st0 < nstage; st0 += D) {
 #pragma unroll
-    for (int q = 0; q < BK / 4; ++q) {
-      const f2v_t a = *(const f2v_t *)&As[buf][q * 4 + lk][wave * 32 + 2 * lr];
-      const f4v_t b = *(const f4v_t *)&Xs[buf][q * 4 + lk][4 * lr];
+    for (int i = 0; i < D; ++i) {
+      const int st = st0 + i;
+      if (st < nstage) {  // (uniform)
+        const int buf = st & 1;
+        fetch(st + D, ra[i], rx[i]);
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[h], acc[0][h], 0, 0, 0);
-        acc[1][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[h], acc[1][h], 0, 0, 0);
+        for (int q = 0; q < BK / 4; ++q) {
+          const f2v_t a = *(const f2v_t *)&As[buf][q * 4 + lk][wave * 32 + 2 * lr];
+          const f4v_t b = *(const f4v_t *)&Xs[buf][q * 4 + lk][4 * lr];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[h], acc[0][h], 0, 0, 0);
+            acc[1][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[h], acc[1][h], 0, 0, 0);
+          }
+        }
+        if (st + 1 < nstage) stash(buf ^ 1, ra[(i + 1) % D], rx[(i + 1) % D]);
+        __syncthreads();
       }
     }
-    if (st + 1 < nstage) stash(buf ^ 1);
-    __syncthreads();
   }
   // C/D of the f32 16x16x4 form: column lane & 15, row 4 (lane >> 4) + reg (the f64 form differs: cdna_hip_programming.md §3)
   float *out = raw + (int64_t)kz * raw_stride + poff + col0 + 4 * lr;
