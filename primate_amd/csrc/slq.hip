@@ -846,7 +846,11 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
       d[kDescRow0] = r0;
       d[kDescRows] = rows;
       const int32_t nd = (D + R - 1) / R;
-      for (int32_t c = 0; c < nd * R; ++c) d[(size_t)(c % R) * 64 + kDescList + c / R] = tile_cols[(size_t)tile_ptr[t] + std::min(c, D - 1)];
+      if (R == 1) {  // (de-interleaved: even lines, then odd ones - slq_common.hpp: ring1_list_pos)
+        for (int32_t c = 0; c < D; ++c) d[kDescList + ring1_list_pos(c)] = tile_cols[(size_t)tile_ptr[t] + c];
+      } else {
+        for (int32_t c = 0; c < nd * R; ++c) d[(size_t)(c % R) * 64 + kDescList + c / R] = tile_cols[(size_t)tile_ptr[t] + std::min(c, D - 1)];
+      }
     }
   });
   if (!ok) throw std::bad_alloc();

@@ -126,6 +126,11 @@ constexpr int kRingSpinMax = 1 << 20;         // ~0.1 s of polling
 constexpr int kRingMaxR = 3;                  // ring columns per step served (more: 128 VGPRs at 16 waves do not hold the sums)
 // descriptor words (tile_desc[t * 64 + ...])
 constexpr int kDescCols = 0, kDescRecOff = 1, kDescRecChunks = 2, kDescRow0 = 3, kDescRows = 4, kDescList = 8;
+// The line list of an R = 1 descriptor is stored de-interleaved (r03): line d at word kDescList + ring1_list_pos(d), i.e. the
+// even lines first, then the odd ones - the lines of each of TWO loader waves are then consecutive words, which a loader
+// fetches with two wide scalar loads instead of eighteen single ones (slq_ring.hpp). Merged tiles (R > 1) keep line d at d.
+constexpr int kRing1ListHalf = (kRingTileCols + 1) / 2;
+__host__ __device__ inline int ring1_list_pos(int d) { return (d & 1) * kRing1ListHalf + (d >> 1); }
 // record words: [0 .. rows] row offsets into the record's own nonzeros, [15] byte offset of the values,
 // [16 .. 16 + rows) line of each row's own panel row, then from byte 128 the column lines (int32) and the values (F)
 constexpr int kRecValOff = 15, kRecSelf = 16, kRecHeadBytes = 128;

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(kRingBlock) void k_csr_ring_pass(
           unsigned char *img = slots + (size_t)slot * kSlotBytes;
           const int D = lane_bcast(dcur, kDescCols);
           for (int d = wave; d < D; d += kRingLoaders) {
-            const int col = lane_bcast(dcur, kDescList + d);
+            const int col = lane_bcast(dcur, kDescList + ring1_list_pos(d));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)col * PW),
                                              (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
             ++issued;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
 #pragma unroll
       for (int i = 0; i < MAXI; ++i) {
         const int dd = min(wave + i * NL, nd - 1);
-        int col = lane_bcast(d[0], kDescList + dd);
+        int col = lane_bcast(d[0], kDescList + (R == 1 ? ring1_list_pos(dd) : dd));
 #pragma unroll
         for (int b = 1; b < R; ++b) {
           const int cb = lane_bcast(d[b], kDescList + dd);
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       o.recoff = dsc[kDescRecOff];
       o.chunks = dsc[kDescRecChunks];
 #pragma unroll
-      for (int u = 0; u < MAXU; ++u) o.c[u] = dsc[kDescList + wave + u * RG::kLoaders];
+      for (int u = 0; u < MAXU; ++u)  // line wave + u kLoaders; two loaders: consecutive words (ring1_list_pos), fetched as wide loads
+        o.c[u] = RG::kLoaders == 2 ? dsc[kDescList + wave * kRing1ListHalf + u] : dsc[kDescList + ring1_list_pos(wave + u * RG::kLoaders)];
     };
     TileDesc cur;
     fetch_desc(0, cur);

@@ -862,11 +862,12 @@ def test_ring_fed_passes_every_panel_width_and_ring_depth(oracle, eng, monkeypat
 	op.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"SLQ_RING_PAD_ROWS": "0"}, {"SLQ_SYM_ALPHA": "0"}])
+@pytest.mark.parametrize("env", [{}, {"SLQ_RING_PAD_ROWS": "0"}, {"SLQ_SYM_ALPHA": "0"}, {"SLQ_RING_STAGED": "1"}, {"SLQ_RING_STAGED": "0"}])
 def test_alpha_pass_stream_forms(oracle, eng, monkeypatch, env):
 	"""The alpha-only ring pass (q_c^T A q_c, src/primate/include/lanczos.h:127-129) on its three streams: the upper triangle
 	with rows padded to whole chunks of four entries (the branch-free consumer, default), the same stream unpadded
-	(SLQ_RING_PAD_ROWS=0), the full rows (SLQ_SYM_ALPHA=0: what a non-symmetric pattern gets) - wide, 64- and 20-probe panels,
+	(SLQ_RING_PAD_ROWS=0), the full rows (SLQ_SYM_ALPHA=0: what a non-symmetric pattern gets), and with either kind of loader forced
+	on every panel width (SLQ_RING_STAGED: through registers / LDS-DMA) - wide, 64- and 20-probe panels,
 	orth 0 (alpha + update) and 3 (Gram sequence), on a 5-point grid (3 upper entries per row: one padded chunk) and on a band
 	with gaps whose rows hold 1..6 upper entries (one or two chunks, differing between the rows a wave walks together)."""
 	rng = np.random.default_rng(77)
