@@ -1978,9 +1978,10 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u, p->rs_u_padded = m.u_padded;
         for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
       }
-      // alpha-only pass: loaders through registers on the merged tiles of narrow panels (measured: 100^3, 64 probes 0.255 -> 0.221 ms,
-      // configs[1] 0.160 -> 0.148), LDS-DMA on wide panels (0.54 against 0.56 ms). SLQ_RING_STAGED=0/1 forces either.
-      p->ring_staged = env_int("SLQ_RING_STAGED", p->ringR > 1 ? 1 : 0) != 0;
+      // alpha-only pass: LDS-DMA loaders everywhere since their r03 rewrite (merged tiles: a lane reads its lines' sources straight
+      // out of the staged descriptor - 100^3, 64 probes 0.230 -> 0.187 ms against the register-staged loaders that had been the
+      // faster form there, configs[1] 0.129 -> 0.113). SLQ_RING_STAGED=1 takes the loaders through registers (GEO 1) again.
+      p->ring_staged = env_int("SLQ_RING_STAGED", 0) != 0;
       // the Gram sequence needs every step of the window on k_ring_pass (PASS_UPDATEG), i.e. the deep form too
       p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && env_int("SLQ_GRAM", 1) != 0;
     }

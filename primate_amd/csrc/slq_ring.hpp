@@ -336,13 +336,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     // tile k's DMAs; w_k: the counted wait). w_k leaves outstanding exactly what was issued after D_k+2 - the DMAs of tiles
     // k + 2 - LAG .. k and the LAG - 2 descriptors k + 3 .. k + LAG - so tile k + 1 - LAG has landed (it is published) and so has
     // descriptor k + 2, which iteration k + 1 reads ahead.
-    auto desc_addr = [&](int k, int b) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + b) * 256) + lane * 4; };
-    int dcur[R], dv = 0, ab = 0;
+    // A lane's source of line d is word kDescList + d of ITS lane group's descriptor block: read straight out of the staged
+    // descriptor, one ds_read_b32 per line with a per-lane base (r03, late: the loader took R v_readlanes and R - 1 selects per
+    // line, 11-15 instructions per DMA - the narrow panels' alpha pass is bound by its loaders). All of a tile's reads go out
+    // together in the read-ahead and are waited for once.
+    constexpr int MAXU = (RG::kLines + RG::kLoaders - 1) / RG::kLoaders;  // lines of a tile per loader at most
+    static_assert(MAXU <= 18, "the read-ahead's operand list");
+    auto block0_addr = [&](int k) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R) * 256) + lane * 4; };
+    auto lines_addr = [&](int k) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + g) * 256) + (kDescList + wave) * 4; };
+    int d0cur = 0, dv = 0, ab = 0;
+    int cc[18], cn[18];
+#pragma unroll
+    for (int u = 0; u < 18; ++u) cc[u] = cn[u] = 0;
+#define SLQ_RD_LINE(U)                                                                                                              \
+  if constexpr (U < MAXU) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(cn[U]) : "v"(la), "n"(U * RG::kLoaders * 4) : "memory");
+#define SLQ_RD_LINES                                                                                                                \
+  SLQ_RD_LINE(0) SLQ_RD_LINE(1) SLQ_RD_LINE(2) SLQ_RD_LINE(3) SLQ_RD_LINE(4) SLQ_RD_LINE(5) SLQ_RD_LINE(6) SLQ_RD_LINE(7) SLQ_RD_LINE(8)        \
+  SLQ_RD_LINE(9) SLQ_RD_LINE(10) SLQ_RD_LINE(11) SLQ_RD_LINE(12) SLQ_RD_LINE(13) SLQ_RD_LINE(14) SLQ_RD_LINE(15) SLQ_RD_LINE(16) SLQ_RD_LINE(17)
+#define SLQ_WAIT_LINES(D0, DV, AB)                                                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                               \
+               : "+v"(D0), "+v"(DV), "+v"(AB), "+v"(cn[0]), "+v"(cn[1]), "+v"(cn[2]), "+v"(cn[3]), "+v"(cn[4]), "+v"(cn[5]), "+v"(cn[6]), "+v"(cn[7]),  \
+                 "+v"(cn[8]), "+v"(cn[9]), "+v"(cn[10]), "+v"(cn[11]), "+v"(cn[12]), "+v"(cn[13]), "+v"(cn[14]), "+v"(cn[15]), "+v"(cn[16]), "+v"(cn[17])    \
+               :                                                                                                                   \
+               : "memory")
     stage_desc(0);
     stage_desc(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const unsigned la = lines_addr(0);
+      asm volatile("ds_read_b32 %0, %1" : "=&v"(d0cur) : "v"(block0_addr(0)) : "memory");
+      SLQ_RD_LINES
+      SLQ_WAIT_LINES(d0cur, dv, ab);
 #pragma unroll
-    for (int b = 0; b < R; ++b) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dcur[b]) : "v"(desc_addr(0, b)) : "memory");
+      for (int u = 0; u < MAXU; ++u) cc[u] = cn[u];
+    }
 #pragma unroll
     for (int i = 2; i <= LAG; ++i) stage_desc(i);  // (descriptor LAG goes where descriptor 0 was: read just above)
     int hist[LAG - 1];  // DMAs issued for tiles k, k - 1, ... (the ones that may still be in flight before tile k + 1)
@@ -369,36 +396,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
 #endif
         if (ok) {
           unsigned char *img = slots + (size_t)slot * RG::kSlotBytes;
-          const int D = lane_bcast(dcur[0], kDescCols);
+          const int D = lane_bcast(d0cur, kDescCols);
           const int nd = (D + R - 1) / R;
           // lane group b lands line d * R + b (block b of the descriptor); past the tile's last line the descriptor repeats
           // that line: it lands once more, in a line nobody reads (a lane's destination is fixed by its number)
-          auto line_col = [&](int d) {
-            int col = lane_bcast(dcur[0], kDescList + d);
 #pragma unroll
-            for (int b = 1; b < R; ++b) {
-              const int cb = lane_bcast(dcur[b], kDescList + d);
-              col = g == b ? cb : col;
+          for (int u = 0; u < MAXU; ++u) {
+            const int d = wave + u * RG::kLoaders;
+            if (d < nd) {
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)cc[u] * PW),
+                                               (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
+              ++issued;
             }
-            return col;
-          };
-          auto land = [&](int col, int d) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wcl + (int64_t)col * PW),
-                                             (__attribute__((address_space(3))) void *)(img + (size_t)d * 1024), 16, 0, SLQ_RING_AUX);
-          };
-          int d = wave;
-          for (; d + RG::kLoaders < nd; d += 2 * RG::kLoaders) {  // two lines per turn: two independent address chains
-            const int c0 = line_col(d), c1 = line_col(d + RG::kLoaders);
-            land(c0, d);
-            land(c1, d + RG::kLoaders);
-            issued += 2;
           }
-          if (d < nd) {
-            land(line_col(d), d);
-            ++issued;
-          }
-          const int chunks = lane_bcast(dcur[0], kDescRecChunks);
-          const char *rsrc = tile_rec + (int64_t)lane_bcast(dcur[0], kDescRecOff) * 16 + lane * 16;
+          const int chunks = lane_bcast(d0cur, kDescRecChunks);
+          const char *rsrc = tile_rec + (int64_t)lane_bcast(d0cur, kDescRecOff) * 16 + lane * 16;
           for (int c = wave; c < chunks; c += RG::kLoaders) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rsrc + c * 1024),
                                              (__attribute__((address_space(3))) void *)(img + RG::kLines * 1024 + c * 1024), 16, 0, 0);
@@ -414,19 +426,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       if (auto *q = dbg_of(k + 1)) q[0] = __builtin_amdgcn_s_memrealtime();
 #endif
       // ---- what precedes tile k + 1 ----
-      // read ahead: descriptor k + 1 (landed: w_k-1, or the prologue's wait), its slot's counter, the abort flag
-      int dnew[R], dvn, abn;
+      // read ahead: descriptor k + 1 (landed: w_k-1, or the prologue's wait) - its head block and this lane's lines -, its
+      // slot's counter, the abort flag
+      int d0new, dvn, abn;
       {
-        const unsigned da = (unsigned)(uintptr_t)(done + (k + 1) % NS), aa = (unsigned)(uintptr_t)abort_f;
-        if constexpr (R == 1)
-          asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5" : "=&v"(dnew[0]), "=&v"(dvn), "=&v"(abn) : "v"(desc_addr(k + 1, 0)), "v"(da), "v"(aa) : "memory");
-        else if constexpr (R == 2)
-          asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7"
-                       : "=&v"(dnew[0]), "=&v"(dnew[1]), "=&v"(dvn), "=&v"(abn) : "v"(desc_addr(k + 1, 0)), "v"(desc_addr(k + 1, 1)), "v"(da), "v"(aa) : "memory");
-        else
-          asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8\n\tds_read_b32 %3, %9\n\tds_read_b32 %4, %10\n\tds_read_b32 %5, %11"
-                       : "=&v"(dnew[0]), "=&v"(dnew[1]), "=&v"(dnew[2]), "=&v"(dnew[3]), "=&v"(dvn), "=&v"(abn)
-                       : "v"(desc_addr(k + 1, 0)), "v"(desc_addr(k + 1, 1)), "v"(desc_addr(k + 1, 2)), "v"(desc_addr(k + 1, 3)), "v"(da), "v"(aa) : "memory");
+        const unsigned la = lines_addr(k + 1);
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5"
+                     : "=&v"(d0new), "=&v"(dvn), "=&v"(abn)
+                     : "v"(block0_addr(k + 1)), "v"((unsigned)(uintptr_t)(done + (k + 1) % NS)), "v"((unsigned)(uintptr_t)abort_f)
+                     : "memory");
+        SLQ_RD_LINES
       }
 #pragma unroll
       for (int i = LAG - 2; i > 0; --i) hist[i] = hist[i - 1];
@@ -436,18 +445,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
       for (int i = 0; i < LAG - 1; ++i) since += hist[i];
       wait_vmcnt_at_most(__builtin_amdgcn_readfirstlane(since));
       if (k + 1 >= LAG && lane == 0) bump(ready + (k + 1 - LAG) % NS);
-      if constexpr (R == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dvn), "+v"(abn)::"memory");
-      else if constexpr (R == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dnew[1]), "+v"(dvn), "+v"(abn)::"memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dnew[0]), "+v"(dnew[1]), "+v"(dnew[2]), "+v"(dnew[3]), "+v"(dvn), "+v"(abn)::"memory");
-#pragma unroll
-      for (int b = 0; b < R; ++b) dcur[b] = dnew[b];
+      SLQ_WAIT_LINES(d0new, dvn, abn);
+      d0cur = d0new;
       dv = dvn;
       ab = abn;
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) cc[u] = cn[u];
       stage_desc(k + 1 + LAG);  // (into descriptor k + 1's place: read and waited for just above)
 #ifdef SLQ_DEBUG_TIMES
       if (auto *q = dbg_of(k + 1)) q[1] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+#undef SLQ_RD_LINE
+#undef SLQ_RD_LINES
+#undef SLQ_WAIT_LINES
   } else if (ntiles > 0) {
     // ---------------- consumer ----------------
     const int cwv = wave - RG::kLoaders;
