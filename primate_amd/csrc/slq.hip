@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -315,15 +316,20 @@ struct UploadQueue {
   hipError_t err = hipSuccess;
   explicit UploadQueue(int dev) : device(dev) {}
   void push(std::vector<Job> jobs) {
-    th.emplace_back([this, jobs = std::move(jobs)] {
+    auto run = [this](const std::vector<Job> &js) {
       hipError_t e = hipSetDevice(device);
-      for (const Job &j : jobs)
+      for (const Job &j : js)
         if (e == hipSuccess && j.bytes) e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
       if (e != hipSuccess) {
         std::lock_guard<std::mutex> g(m);
         if (err == hipSuccess) err = e;
       }
-    });
+    };
+    try {
+      th.emplace_back([run, jobs]() { run(jobs); });
+    } catch (const std::system_error &) {  // no thread to be had: the caller copies
+      run(jobs);
+    }
   }
   hipError_t wait() {
     for (auto &t : th)
@@ -922,6 +928,9 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   } catch (const std::bad_alloc &) {
     if (out) *out = nullptr;
     return fail(SLQ_ENOMEM, "host allocation failed while analysing the operator");
+  } catch (const std::exception &e) {  // (e.g. no thread to be had)
+    if (out) *out = nullptr;
+    return fail(SLQ_EHIP, "operator analysis failed: %s", e.what());
   }
 }
 
@@ -957,6 +966,14 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (!op) return fail(SLQ_ENOMEM, "host allocation failed");
   ctx_retain(ctx);
   *op = slq_operator{ctx, OP_CSR, dtype, n, nnz, nullptr, nullptr, nullptr, 0, true, nullptr, nullptr, nullptr, nullptr, TileMeta{}};
+  // whatever way this function is left without handing `op` out - an error return below or an exception of the host-side
+  // analysis - the operator and what it owns on the device go with it (declared before the upload queue: that one joins first)
+  struct OpGuard {
+    slq_operator *op;
+    ~OpGuard() {
+      if (op) slq_operator_destroy(op);
+    }
+  } guard{op};
   const size_t es = esize(dtype);
   // optional XCD-aware reordering: A' = P A P^T stored, vectors live in the permuted row space
   std::vector<int32_t> rp2;
@@ -1090,7 +1107,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     std::vector<int32_t> order;
     if (cluster_tiles(&rcm_order(), order)) {
       have_tiles = true;
-      if (!adopt(order)) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+      if (!adopt(order)) { return fail(SLQ_ENOMEM, "host allocation failed"); }
     } else if (sub_env <= 0) {
       rcm_perm.clear();  // declined: the generic passes keep their own (one-piece) order, decided below
     }
@@ -1104,7 +1121,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   }
   if (want) {
     op->perm_h = new (std::nothrow) std::vector<int32_t>();
-    if (!op->perm_h) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+    if (!op->perm_h) { return fail(SLQ_ENOMEM, "host allocation failed"); }
     std::vector<int32_t> &perm = *op->perm_h;
     perm = rcm_order();
     std::vector<int32_t> inv((size_t)n);
@@ -1122,7 +1139,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     std::vector<int32_t> order;
     if (cluster_tiles(op->perm_h, order)) {
       have_tiles = true;
-      if (!adopt(order)) { slq_operator_destroy(op); return fail(SLQ_ENOMEM, "host allocation failed"); }
+      if (!adopt(order)) { return fail(SLQ_ENOMEM, "host allocation failed"); }
     }
   }
   if (have_tiles) {
@@ -1144,7 +1161,6 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   auto bail = [&](int code, const char *what, hipError_t e) {
     up.wait();
     hipStreamSynchronize(ctx->stream);
-    slq_operator_destroy(op);
     return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : code, "%s: %s", what, hipGetErrorString(e));
   };
   if (op->perm_h) {
@@ -1180,8 +1196,6 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       }
     });
     if (!pok) {
-      up.wait();
-      slq_operator_destroy(op);
       return fail(SLQ_ENOMEM, "host allocation failed");
     }
     rowptr = rp2.data();
@@ -1310,6 +1324,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (e != hipSuccess) return bail(SLQ_EHIP, "operator upload", e);
   clk.lap("uploads drained");
   clk.total("all of slq_csr_create");
+  guard.op = nullptr;
   *out = op;
   return SLQ_OK;
 }
