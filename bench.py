@@ -9,12 +9,15 @@ device, 30 lock-step Lanczos steps, on-device Gauss quadrature, sum f(theta)*tau
 operator is resident in HBM before the timed region. Probes shard across GPUs with no data-path
 collective (weak scaling: 256 probes per GPU; probe ids are global, so results do not depend on N).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--orth R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--orth R] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With --gpus N > 1 and no WORLD_SIZE in the environment (a bare `python bench.py --gpus N`) the process starts its own N
 ranks (spawn_ranks: child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything here touches
 torch or HIP), relays rank 0's line and exits with the worst child's code.
+
+--scaling strong: --probes is the GLOBAL batch of a step and rank r advances its contiguous shard (256 probes over 8 GPUs =
+32 per GPU, the narrow-panel plans); the line then says "scaling": "strong". Default: weak (256 per GPU).
 
 Prints ONE JSON line on rank 0.
 """
@@ -131,7 +134,9 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 			ch = 8 if half else chunk  # slq_kernels.hpp: kReorthChunk32 / kReorthChunk
 			for i0 in range(0, r, ch):
 				rc = min(ch, r - i0)
-				out["reorth_dot"] += (cols(i0, i0 + rc) + (2 if i0 == 0 else 1)) * vec
+				## plain ring: every dots chunk is read-only since r04 (the axpy `w -= cB W_c` is applied in registers and stored by the
+				## update sweep): w + the chunk's columns, and W_c once more in later chunks; the archive form stores in its first chunk
+				out["reorth_dot"] += (cols(i0, i0 + rc) + ((2 if i0 == 0 else 1) if half else (1 if i0 == 0 else 2))) * vec
 				launches["reorth_dot"] += 1
 			out["reorth_update"] += (cols(0, r) + 2 + (0.5 if half else 0.0)) * vec
 			launches["reorth_update"] += 1
@@ -167,8 +172,17 @@ def kernel_sources_sha256():
 	return h.hexdigest()
 
 
-def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank, world, dist, red_dev, profiled=True, stream_rates=True):
-	"""One bench measurement: `warmup` untimed + `steps` timed passes of the hot path on `workload`; returns the JSON line."""
+def shard_range(nprobes, rank, world):
+	"""Contiguous block [lo, hi) of global probe ids owned by `rank` (primate_amd.distributed.shard_range; first ranks take the remainder)."""
+	base, rem = divmod(int(nprobes), int(world))
+	lo = rank * base + min(rank, rem)
+	return lo, lo + base + (1 if rank < rem else 0)
+
+
+def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank, world, dist, red_dev, profiled=True, stream_rates=True, scaling="weak"):
+	"""One bench measurement: `warmup` untimed + `steps` timed passes of the hot path on `workload`; returns the JSON line.
+	scaling = "weak": every rank advances P probes per step; "strong": P is the GLOBAL batch of a step and rank r advances its
+	contiguous shard of it (256 probes over 8 GPUs = 32 per GPU: the narrow-panel plans; src/primate/trace.py:36 draws 32 per batch)."""
 	import torch
 
 	from primate_amd.engine import DeviceOperator, LanczosPlan
@@ -177,14 +191,26 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	np_dt = np.float64 if dtype == "f64" else np.float32
 	A = laplacian_2d(int(m), dtype=np_dt) if kind == "lap2d" else laplacian_3d(int(m), dtype=np_dt)
 	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
+	t_create = time.perf_counter()
 	op = DeviceOperator(A, ctx=ctx)  # CSR resident in HBM before the timed region
+	ctx.synchronize()
+	create_s = time.perf_counter() - t_create  # host analysis (reordering, tiles, streams) + upload: what a one-shot call pays on top
 	deg = min(deg_req, n)
 	orth = deg if orth_req < 0 or orth_req > deg else orth_req
+	P_global = P * world if scaling == "weak" else P  # probes of one step over all ranks
+	if scaling == "strong":
+		lo, hi = shard_range(P_global, rank, world)
+		assert hi > lo, f"--scaling strong: {P_global} probes do not reach rank {rank} of {world}"
+		P = hi - lo
+	else:
+		lo = rank * P
+	t_plan = time.perf_counter()
 	plan = LanczosPlan(op, P, deg, orth)
+	plan_s = time.perf_counter() - t_plan
 
 	def step(it: int):
-		## probe ids are global: rank r draws ids [ (it*world + r) * P, ... + P )
-		plan.generate_probes("rademacher", seed=1234, probe_offset=(it * world + rank) * P)
+		## probe ids are global: step `it` draws ids [it * P_global, (it + 1) * P_global), rank r its block of them
+		plan.generate_probes("rademacher", seed=1234, probe_offset=it * P_global + lo)
 		plan.run(1e-8)
 		q = plan.quadrature(fun)  # device QL + reduction; returns P doubles (synchronises)
 		if dist is not None:
@@ -233,7 +259,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	else:
 		estimate = float(np.mean(np.concatenate(ests)))
 
-	probe_matvecs = world * P * deg * steps
+	probe_matvecs = P_global * deg * steps
 	value = probe_matvecs / elapsed
 	ms_per_step = elapsed / steps * 1e3
 
@@ -271,26 +297,35 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	line = {
 		"metric": "probe-matvecs/sec", "value": round(value, 1), "unit": "probe-matvecs/s", "n_gpus": world,
 		"steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-		"scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+		"scaling": scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
 		"config": {
-			"workload": f"{'configs[1]: logdet via SLQ' if workload == 'lap2d_1000' and dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={fun}",
-			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "resident_probes_b": P,
+			"workload": f"{'configs[1]: logdet via SLQ' if workload == 'lap2d_1000' and dtype == 'f64' else 'SLQ trace'}, {'2D 5-point' if kind == 'lap2d' else '3D 7-point'} Laplacian CSR n={n} nnz={nnz}, k={deg}, {P} Rademacher probes per GPU (device Philox), f={fun}"
+			+ (f" [strong scaling: {P_global} probes per step over {world} GPUs]" if scaling == "strong" else ""),
+			"n": n, "nnz": int(nnz), "deg": deg, "orth": orth, "probes_per_gpu": P, "probes_per_step_global": P_global, "resident_probes_b": P,
+			"panel_width": info["panel_width"], "create_s": round(create_s, 4), "plan_s": round(plan_s, 4),
 			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused), "plan": info,
 			"kernel_events_in_timed_region": bool(profiled),
 		},
-		"trace_estimates_per_s": round(world * P * steps / elapsed, 1),
+		"trace_estimates_per_s": round(P_global * steps / elapsed, 1),
 		"estimate": float(estimate),
 		"roofline": roofline,
 		"loop": {
 			"contract_bytes_per_probe_matvec": int(contract),
 			"contract_GBps_per_gpu": round(value / world * contract / 1e9, 1),
 			"contract_frac_of_peak": round(value / world * contract / 1e9 / HBM_PEAK_GBS, 4),
+			## the implementation's OWN algorithmic bytes (kernel_bytes: every launch of the step) over the step's wall time
+			"own_bytes_per_step": int(sum(kb.values())),
+			"own_bytes_GBps": round(sum(kb.values()) / (elapsed / steps) / 1e9, 1),
+			"own_bytes_frac_of_peak": round(sum(kb.values()) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4),
 		},
 		"kernels": kernels,
 	}  # fmt: skip
 
 	del plan, op
 	return {"line": line, "A": A, "n": n, "deg": deg, "orth": orth}
+
+
+SPAWN_TIMEOUT_S = 3000.0  # overall limit of a self-launched N-rank run (--timeout)
 
 
 def spawn_ranks(n, argv, cmd=None, timeout=None):
@@ -315,24 +350,38 @@ def spawn_ranks(n, argv, cmd=None, timeout=None):
 		env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
 		## rank 0 owns the JSON line; whatever other ranks print goes to stderr so that stdout stays ONE line
 		procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+	## Watch EVERY child, not only rank 0: a rank that dies before or inside a collective leaves the others blocked in it (rank 0
+	## included), so the first non-zero exit ends the rest - the children started here, by handle - and the run reports failure
+	## instead of holding the GPUs until a watchdog fires. Rank 0's stdout is drained by a thread meanwhile (a full pipe would
+	## block it).
+	import threading
+
+	chunks = []
+	rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+	rd.start()
 	t_end = None if timeout is None else time.monotonic() + timeout
-	out0 = b""
-	try:
-		out0, _ = procs[0].communicate(timeout=timeout)
-		for p in procs[1:]:
-			p.wait(timeout=None if t_end is None else max(1.0, t_end - time.monotonic()))
-	except subprocess.TimeoutExpired:
-		pass
-	finally:
-		for p in procs:  # exactly the children started above, nothing by pattern
-			if p.poll() is None:
-				p.terminate()
-		for p in procs:
-			try:
-				p.wait(timeout=20)
-			except subprocess.TimeoutExpired:
-				p.kill()
-				p.wait()
+	timed_out = False
+	while True:
+		codes = [p.poll() for p in procs]
+		if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+			break
+		if t_end is not None and time.monotonic() > t_end:
+			timed_out = True
+			break
+		time.sleep(0.05)
+	for p in procs:  # exactly the children started above, nothing by pattern
+		if p.poll() is None:
+			p.terminate()
+	for p in procs:
+		try:
+			p.wait(timeout=20)
+		except subprocess.TimeoutExpired:
+			p.kill()
+			p.wait()
+	rd.join(timeout=20)
+	out0 = b"".join(c for c in chunks if c)
+	if timed_out:
+		print(f"bench.py: ranks still running after {timeout:.0f} s were ended", file=sys.stderr)
 	## stdout stays ONE line: rank 0's JSON record. Anything else a rank-0 library printed there (gloo announces its peers on
 	## stdout) is passed on through stderr
 	for ln in out0.decode(errors="replace").splitlines():
@@ -359,11 +408,14 @@ def main():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-extra", action="store_true", help="skip the extra operators appended to the default line")
 	ap.add_argument("--cpu-seconds", type=float, default=15.0)
+	ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+	                help="weak: --probes per GPU (default); strong: --probes is the GLOBAL count, rank r takes its contiguous shard")
+	ap.add_argument("--timeout", type=float, default=SPAWN_TIMEOUT_S, help="overall limit (s) of a self-launched N-rank run")
 	args = ap.parse_args()
 
 	N = args.gpus
 	if N > 1 and "WORLD_SIZE" not in os.environ:
-		sys.exit(spawn_ranks(N, sys.argv[1:]))  # a bare `python bench.py --gpus N`: be the launcher (torch is not imported yet)
+		sys.exit(spawn_ranks(N, sys.argv[1:], timeout=args.timeout))  # a bare `python bench.py --gpus N`: be the launcher (torch is not imported yet)
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -393,7 +445,7 @@ def main():
 
 	ctx = Context(device=local_rank)
 	res = measure(ctx, args.workload, args.dtype, args.probes, args.deg, args.orth, args.steps, args.warmup, args.fun,
-				  rank, world, dist, red_dev, profiled=not os.environ.get("BENCH_NO_PROFILE"))
+				  rank, world, dist, red_dev, profiled=not os.environ.get("BENCH_NO_PROFILE"), scaling=args.scaling)
 	line, A, n, deg, orth = res["line"], res["A"], res["n"], res["deg"], res["orth"]
 	line["steps"], line["warmup"] = args.steps, args.warmup
 
@@ -423,10 +475,15 @@ def main():
 			"lap3d_100_orth3": ("lap3d_100", 3, 256), "lap3d_100_orth0": ("lap3d_100", 0, 256), "lap2d_1000_orth0": ("lap2d_1000", 0, 256),
 			"lap3d_100_orth3_p64": ("lap3d_100", 3, 64), "lap2d_1000_orth3_p64": ("lap2d_1000", 3, 64), "lap2d_1000_orth6": ("lap2d_1000", 6, 256),
 		}  # fmt: skip
-		for key, (w, o, pr) in cases.items():
-			r = measure(ctx, w, "f64", pr, 30, o, 3, 1, args.fun, 0, 1, None, red_dev, profiled=True, stream_rates=False)["line"]
+		## ... and the north_star's wording of the inner loop, "with full reorthogonalization" (orth = k: lanczos.h:133-136; operators.py:77,80
+		## clamp out-of-range orth to deg): 2 timed steps each, ~0.4 s per step on a 64 GB ring
+		cases.update({"lap2d_1000_orth30": ("lap2d_1000", 30, 256, 2), "lap3d_100_orth30": ("lap3d_100", 30, 256, 2)})
+		for key, (w, o, pr, *st) in cases.items():
+			nst = st[0] if st else 3
+			r = measure(ctx, w, "f64", pr, 30, o, nst, 1, args.fun, 0, 1, None, red_dev, profiled=True, stream_rates=False)["line"]
 			extra[key] = {
-				"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+				"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": nst, "warmup": 1,
+				"create_s": r["config"]["create_s"], "own_bytes_frac_of_peak": r["loop"]["own_bytes_frac_of_peak"], "sequence": r["config"]["plan"]["sequence"],
 				"workload": r["config"]["workload"], "nnz": r["config"]["nnz"], "estimate": r["estimate"],
 				"roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "alg_bytes_per_launch", "avg_launch_ms", "launches")},
 				"kernels": r["kernels"],

@@ -274,6 +274,7 @@ enum {
   SLQ_K_FINALIZE,    /* all per-step scalar kernels (partials -> alpha/beta/coefficients)           */
   SLQ_K_PROBES,      /* probe generation / layout                                                   */
   SLQ_K_QUADRATURE,  /* tridiagonal eigensolve + f reduction                                        */
+  SLQ_K_COMBINE,     /* f(A)x = sum_t g_t W_t over the kept basis (slq_plan_fun_action; not a recurrence sweep) */
   SLQ_K_COUNT
 };
 typedef struct {

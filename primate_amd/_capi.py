@@ -23,7 +23,7 @@ FUN_IDS = {
 	"softsign": 8,
 }  # fmt: skip
 PDF_IDS = {"rademacher": 0, "signs": 0, "normal": 1, "gaussian": 1, "sphere": 2}
-KERNEL_CLASSES = ["spmm_3term", "axpy_norm", "reorth_dot", "reorth_update", "finalize", "probes", "quadrature"]
+KERNEL_CLASSES = ["spmm_3term", "axpy_norm", "reorth_dot", "reorth_update", "finalize", "probes", "quadrature", "fun_combine"]
 
 MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 

@@ -168,9 +168,10 @@ struct Switches {
   int ring32;      // SLQ_RING32    opt-in: finished Lanczos vectors archived as fp32 for deep reorthogonalisation
   int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
+  int defer_axpy;  // SLQ_DEFER_AXPY the block-CGS sweeps apply `w -= cB W_c` in the update sweep: the dots sweeps are read-only (r04; 0: first chunk stores)
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, dense_lds, pipe, ring32, fused_pad, spmm_pad})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, dense_lds, pipe, ring32, fused_pad, spmm_pad, defer_axpy})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -1920,7 +1921,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
                    tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 2), env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_DENSE_LDS", 1) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
-                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344)};
+                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344), env_int("SLQ_DEFER_AXPY", 1) != 0};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
   p->S = ring_slots(deg, orth, p->keep_basis);
@@ -2615,8 +2616,8 @@ static int apply_operator_unfused(slq_plan *p, int slot_c) {
   return SLQ_OK;
 }
 
-static int launch_reorth_update(slq_plan *p, int j, int r, int istart);
-static int launch_reorth_update_range(slq_plan *p, int j, int ibegin, int iend);
+static int launch_reorth_update(slq_plan *p, int j, int r, int istart, bool axpy = false, int klass = SLQ_K_REORTH_UPD);
+static int launch_reorth_update_range(slq_plan *p, int j, int ibegin, int iend, bool axpy = false, int klass = SLQ_K_REORTH_UPD);
 static int update_chunk_cols(const slq_plan *p);
 
 // probes per workgroup of the QL kernel: 3*deg*lanes doubles of LDS, at most 150 KiB
@@ -2626,6 +2627,8 @@ static int quadrature_lanes(int deg) {
 }
 
 // one dots sweep of the store-and-revisit sequence, with or without the fp32 archive
+// (deferred: the block-CGS sweeps leave `w -= cB W_c` to the update sweep - every dots chunk applies it in registers and stores
+// nothing; the fp32-archive kernels keep the stored form)
 template <typename F, int L> static inline void launch_reorth_dot(slq_plan *p, dim3 gS, hipStream_t st, int j, int i0, int rc) {
   if constexpr (std::is_same<F, double>::value) {
     if (p->ring32_on) {
@@ -2634,10 +2637,11 @@ template <typename F, int L> static inline void launch_reorth_dot(slq_plan *p, d
       return;
     }
   }
-  k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (int)(i0 == 0), p->st.coefB, p->part, p->bpad);
+  k_reorth_dot<F, L><<<gS, dim3(kBlock), 0, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, (p->sw.defer_axpy && !p->ring32_on) ? 2 : (int)(i0 == 0), p->st.coefB, p->part,
+                                                  p->bpad);
 }
 template <typename F, int L>
-static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds, hipStream_t st, int j, int i0, int rc, int archive) {
+static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds, hipStream_t st, int j, int i0, int rc, int archive, bool axpy = false) {
   if constexpr (std::is_same<F, double>::value) {
     if (p->ring32_on) {
       const size_t lds32 = sizeof(double) * kWaves * 64 * 4 + (size_t)rc * p->PW * sizeof(double);
@@ -2647,7 +2651,7 @@ static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds,
     }
   }
   k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, p->st.gamma + (size_t)i0 * p->bpad,
-                                                     p->part, p->bpad);
+                                                     p->part, p->bpad, axpy ? p->st.coefB : nullptr);
 }
 
 // one fused CSR pass; the pipelined row loop exists for one-row-per-wave panels (L == 64) and not for the alpha pass
@@ -2947,7 +2951,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
                  hipLaunchKernelGGL(k_fin_gamma, dim3((bp + 63) / 64, rc), dim3(kFinThreads), 0, st, p->st,
                                     p->part, p->nblkS, j, i0, orth_tol));
       }
-      SLQ_TRY(launch_reorth_update(p, j, r, 0));
+      SLQ_TRY(launch_reorth_update(p, j, r, 0, p->sw.defer_axpy && !p->ring32_on));
     }
     }  // !fused
     PROFILED(p, SLQ_K_FINALIZE,
@@ -3096,7 +3100,8 @@ static int update_chunk_cols(const slq_plan *p) {
 }
 
 // w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
-static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r) {
+// axpy: the first chunk also applies the three-term step's `w -= cB W_c` (the dots sweeps ran in mode 2 and stored nothing)
+static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r, bool axpy, int klass) {
   hipStream_t st = p->ctx->stream;
   const int V = p->dtype == SLQ_F64 ? 2 : 4;
   const int kUpdChunk = update_chunk_cols(p);
@@ -3104,14 +3109,14 @@ static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r) {
   for (int i0 = istart; i0 < r; i0 += kUpdChunk) {
     const int rc = std::min(kUpdChunk, r - i0);
     const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
-    PROFILED(p, SLQ_K_REORTH_UPD,
+    PROFILED(p, klass,
              DISPATCH(p->dtype, p->LPR,
-                      (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r)))));  // last chunk: w is final
+                      (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r), axpy && i0 == istart))));  // last chunk: w is final
   }
   return SLQ_OK;
 }
 
-static int launch_reorth_update(slq_plan *p, int j, int r, int istart) { return launch_reorth_update_range(p, j, istart, r); }
+static int launch_reorth_update(slq_plan *p, int j, int r, int istart, bool axpy, int klass) { return launch_reorth_update_range(p, j, istart, r, axpy, klass); }
 
 // Y = f(A) X on the device: result left in ring slot `deg` (panel layout)
 static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) {
@@ -3144,7 +3149,7 @@ static int fun_action_device(slq_plan *p, int fun_id, const double *fun_params) 
   }
   // output accumulates in slot `deg` (the spare slot behind the basis; it held the last residual)
   HIP_TRY(hipMemsetAsync(slot_ptr(p, deg), 0, (size_t)p->slot_stride * p->esz, st));
-  SLQ_TRY(launch_reorth_update(p, deg - 1, deg, 0));
+  SLQ_TRY(launch_reorth_update(p, deg - 1, deg, 0, false, SLQ_K_COMBINE));  // (its own profile class: these bytes are not the recurrence's update sweep)
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, p->fail_d, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -33,6 +33,8 @@ template <int POLICY, typename VF> __device__ __forceinline__ VF stream_load(con
 template <int POLICY, typename VF> __device__ __forceinline__ void stream_store_impl(VF *p, VF v) {
   if (POLICY == 1) __builtin_nontemporal_store(v, p);
   else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
   else *p = v;
 }
 template <int POLICY> __device__ __forceinline__ void stream_store(
@@ -44,6 +46,12 @@ template <int POLICY> __device__ __forceinline__ void stream_store(
   stream_store_impl<POLICY>(p, v);
 }
 
+#ifndef SLQ_SWEEP_ST
+#define SLQ_SWEEP_ST 0  // store flavour of the in-place sweeps (k_reorth_dot's first chunk, k_reorth_update): A/B builds
+#endif
+#ifndef SLQ_SWEEP_LDW
+#define SLQ_SWEEP_LDW 0  // load flavour of the row that is stored again
+#endif
 constexpr int kBlock = 512;          // threads per workgroup for the sweep kernels (8 waves)
 constexpr int kWaves = kBlock / 64;
 constexpr int kReorthChunk = 16;     // reorth columns whose dot accumulators live in registers

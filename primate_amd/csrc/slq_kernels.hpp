@@ -1603,7 +1603,13 @@ __global__ __launch_bounds__(kBlock) void k_axpy_norm(int n, F *W, const F *Wc,
   block_reduce_columns<F, LPR>(nacc, red, partN + (int64_t)blockIdx.x * bpad + panel * PW);
 }
 
-// ---- sweep B (orth > 0): w -= cB*Wc (first chunk only) ; partD[i] += W_{t_i} . w -----------------
+// ---- sweep B (orth > 0): w -= cB*Wc ; partD[i] += W_{t_i} . w ------------------------------------
+// apply_axpy: 0 - w is final as stored; 1 - the three-term step's `w -= cB W_c` (lanczos.h:130) is applied AND stored (first
+// chunk of the MGS-order and fp32-archive sequences, which update w in place between dots); 2 (r04) - it is applied in
+// registers only: the sweep stays read-only, and k_reorth_update applies the same term (same fma, same order: bitwise the
+// same w) together with its projections and makes the step's one store. A store among 17 read streams costs this sweep a
+// fifth of its rate whatever its flavour (scripts/microbench_reorth.hip: 17 reads 6.5-6.9 TB/s, 17 reads + 1 write 5.2-5.4),
+// a second read of W_c in a later chunk costs 1/16.
 // The reorthogonalisation set is the last r ring vectors t_i = j - i, i = 0..r-1 (reference:
 // orth_vector(v, Q, c, orth, reverse=true), lanczos.h:135 with :58). The reference runs modified
 // Gram-Schmidt (r sequentially dependent dot+axpy passes, lanczos.h:58-65); here all r dots are
@@ -1637,10 +1643,10 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot(
   const int stride = gridDim.x * kWaves * RPW;
   for (int row = (blockIdx.x * kWaves + wave) * RPW + g; row < n; row += stride) {
     const int64_t ro = (int64_t)row * PW;
-    VF w = *(const VF *)(W + ro);
+    VF w = stream_load<SLQ_SWEEP_LDW>((const VF *)(W + ro));
     if (apply_axpy) {
       w -= cb * *(const VF *)(Wc + ro);
-      *(VF *)(W + ro) = w;
+      if (apply_axpy == 1) stream_store<SLQ_SWEEP_ST>((VF *)(W + ro), w);  // (2: in registers only - k_reorth_update applies it again and stores)
     }
     VF u[kReorthChunk];
 #pragma unroll
@@ -1665,7 +1671,7 @@ template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_reorth_update(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int r,
     const double *__restrict__ gamma /* [r][bpad], already offset to column i0 */,
-    double *__restrict__ partN, int bpad) {
+    double *__restrict__ partN, int bpad, const double *__restrict__ coefB /* non-null: w -= cB W_c first (k_reorth_dot mode 2) */) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   constexpr int UR = SLQ_UPD_UR;
@@ -1681,6 +1687,12 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
   __syncthreads();
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
+  const F *Wc = ring + (int64_t)(j % S) * slot_stride + poff;
+  VF cb = (VF)(F)0;
+  if (coefB) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) cb[v] = (F)coefB[panel * PW + cl * V + v];
+  }
   VF nacc = (VF)(F)0;
   // UR CONSECUTIVE row groups per wave and iteration (one contiguous UR*RPW*PW*sizeof(F) block):
   // the gamma read from LDS is amortised over UR rows and UR loads per column are in flight.
@@ -1692,7 +1704,11 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
     for (int u = 0; u < UR; ++u) {
       const int row = r0 + u * RPW;
       ro[u] = (int64_t)(row < n ? row : 0) * PW;
-      w[u] = *(const VF *)(W + ro[u]);
+      w[u] = stream_load<SLQ_SWEEP_LDW>((const VF *)(W + ro[u]));
+    }
+    if (coefB) {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) w[u] -= cb * *(const VF *)(Wc + ro[u]);  // (the row is read again as column 0 below: an L1 hit)
     }
     for (int i = 0; i < r; ++i) {
       const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
@@ -1707,7 +1723,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
     for (int u = 0; u < UR; ++u) {
       const int row = r0 + u * RPW;
       if (row < n) {
-        *(VF *)(W + ro[u]) = w[u];
+        stream_store<SLQ_SWEEP_ST>((VF *)(W + ro[u]), w[u]);
         nacc += w[u] * w[u];
       }
     }

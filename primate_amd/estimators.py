@@ -166,34 +166,42 @@ class Estimator:
 
 
 class ControlVariableEstimator(MeanEstimator):
-	"""Mean of a scalar response corrected by control variates with known expectations `ecv`
-	(src/primate/estimators.py:148-196): samples are rows [y, c_1, ..., c_m]; the estimate is
-	mean(y) - alpha . (mean(c) - ecv) with alpha = Cov(c)^-1 Cov(c, y) re-estimated at every update unless
-	given."""
+	"""Regression-adjusted mean (control variates; counterpart of src/primate/estimators.py:148-196). A sample is a row
+	[y, c_1 .. c_m]; E[c] = `ecv` is known. One joint scatter accumulator over the m + 1 columns is all the state; the
+	coefficient vector is whatever was given, or else the least-squares slope of y on c, solved from the accumulated
+	covariance blocks whenever it is asked for: a = Cov(c, c)^-1 Cov(c, y). estimate = mean(y) - a . (mean(c) - ecv)."""
 
 	def __init__(self, ecv, alpha=None, record: bool = False):
-		ecv = np.atleast_1d(ecv).astype(float).ravel()
-		super().__init__(len(ecv), covariance=False, record=record)
+		known = np.asarray(ecv, dtype=float).reshape(-1)
+		super().__init__(known.size, covariance=False, record=record)
+		self.ecv = known
+		self._given = None
 		if alpha is not None:
-			alpha = np.atleast_1d(alpha).astype(float).ravel()
-			assert len(alpha) == len(ecv), "Coefficients alpha must have same length as the control variables."
-		self.alpha, self.ecv = alpha, ecv
-		self.cov = Covariance(dim=len(ecv) + 1)
-		self._fit_alpha = alpha is None
+			self._given = np.asarray(alpha, dtype=float).reshape(-1)
+			assert self._given.size == known.size, "Coefficients alpha must have same length as the control variables."
+		self.cov = Covariance(dim=known.size + 1)
+
+	@property
+	def alpha(self):
+		if self._given is not None:
+			return self._given
+		if self.cov.n < 2:
+			return None
+		C = np.atleast_2d(self.cov.covariance(ddof=1))
+		cc, cy = C[1:, 1:], C[1:, 0]
+		return cy / cc[0, 0] if cy.size == 1 else np.linalg.solve(cc, cy)
 
 	def update(self, samples):
 		self.cov.update(np.atleast_1d(samples))
 		self.n_samples = self.cov.n
-		if self._fit_alpha:
-			C = np.atleast_2d(self.cov(ddof=1))
-			self.alpha = np.atleast_1d(C[0, 1] / C[1, 1]) if self.cov.dim == 2 else np.linalg.solve(C[1:, 1:], C[1:, 0])
 		return self
 
 	@property
 	def estimate(self):
 		if self.n_samples == 0:
 			return np.nan
-		return float(self.cov.mu[0] - np.dot(self.alpha, self.cov.mu[1:] - self.ecv))
+		y_bar, c_bar = self.cov.mu[0], self.cov.mu[1:]
+		return float(y_bar - self.alpha @ (c_bar - self.ecv))
 
 
 def arr_summary(x) -> str:
@@ -241,40 +249,48 @@ class ToleranceCriterion(ConvergenceCriterion):
 
 
 class ConfidenceCriterion(ConvergenceCriterion):
-	"""CLT margin of error <= atol or relative standard error <= rtol (estimators.py:246-299):
-	Student-t score below 30 samples, normal score afterwards; never before 3 samples."""
+	"""Stop when the two-sided `confidence` interval of the sample mean is narrow enough: half-width <= atol, or standard error
+	of the mean <= rtol |mean| (counterpart of src/primate/estimators.py:246-299). The critical value is Student's t while
+	fewer than 30 samples were seen - with n + 1 degrees of freedom at n samples, the reference's table as it is indexed -
+	and the normal quantile from there on; below 3 samples nothing is decided."""
+
+	_SMALL = 30  # samples below which the t table is consulted
 
 	def __init__(self, confidence: float = 0.95, atol: float = 0.00, rtol: float = 0.01) -> None:
-		import scipy.special
-		import scipy.stats
+		from scipy.stats import norm, t as student
 
 		assert 0 < confidence and confidence < 1, "Confidence must be in (0, 1)"
-		self.atol = 0.0 if atol is None else atol
-		self.rtol = 0.0 if rtol is None else rtol
-		self.z = np.sqrt(2.0) * scipy.special.erfinv(confidence)
-		self.t_scores = scipy.stats.t.ppf((confidence + 1.0) / 2.0, df=np.arange(30) + 1)
 		self.confidence = confidence
+		self.atol, self.rtol = (atol or 0.0), (rtol or 0.0)
+		upper = 0.5 * (1.0 + confidence)  # two-sided interval -> upper-tail quantile
+		self.z = float(norm.ppf(upper))
+		self.t_scores = student.ppf(upper, df=1 + np.arange(self._SMALL))
+
+	def critical_value(self, n: int) -> float:
+		return float(self.t_scores[n]) if n < self._SMALL else self.z
 
 	def _error(self, est: MeanEstimator) -> tuple:
-		if est.n_samples < 3:
+		"""(half-width of the interval, standard error relative to |mean|)."""
+		n = est.n_samples
+		if n < 3:
 			return (np.inf, np.inf)
-		std_err = est._cov.covariance() ** 0.5 / np.sqrt(est.n_samples)
-		score = self.t_scores[est.n_samples] if est.n_samples < 30 else self.z
-		return (score * std_err, abs(std_err / est.estimate))
+		sem = float(np.sqrt(est._cov.covariance(ddof=1) / n))
+		return (self.critical_value(n) * sem, abs(sem / est.estimate))
 
 	def __call__(self, est) -> bool:
 		assert isinstance(est, MeanEstimator), "Must be a mean estimator"
-		moe, rerr = self._error(est)
-		return moe <= self.atol or rerr <= self.rtol
+		half_width, rel = self._error(est)
+		return half_width <= self.atol or rel <= self.rtol
 
 	def message(self, est) -> str:
-		moe, _ = self._error(est)
-		return f"Est: {_summary(est.estimate)} +/- {moe:.3f} ({self.confidence*100:.0f}% CI, #S:{ len(est) })"
+		return f"Est: {_summary(est.estimate)} +/- {self._error(est)[0]:.3f} ({self.confidence*100:.0f}% CI, #S:{ len(est) })"
 
 
 class KneeCriterion(ConvergenceCriterion):
-	"""Kneedle-style detection of the knee of the cumulative |change| of the running sample mean
-	(estimators.py:302-333). Needs an estimator created with record=True."""
+	"""Stop at the knee of the recorded path (counterpart of src/primate/estimators.py:302-333; needs record=True). The path is
+	the total variation, up to each sample, of the sequence x_i / i. Rescaled to run from 0 to 1 it is compared with the
+	straight line between its end points; the path has a knee once it bulges above that line by more than S / (m - 1),
+	m = number of path points (the path ends ON the line, so the bulge is measured against 0 there)."""
 
 	def __init__(self, S: float = 1.0) -> None:
 		self.S = S
@@ -282,14 +298,14 @@ class KneeCriterion(ConvergenceCriterion):
 	def __call__(self, est) -> bool:
 		if est.values is None or len(est.values) < 3:
 			return False
-		vals = np.array(est.values).ravel()
-		running = vals / np.arange(1, len(vals) + 1)
-		y = np.cumsum(np.abs(np.diff(running)))
-		y_norm = (y - y.min()) / (y.max() - y.min())
-		diff_curve = y_norm - np.linspace(0, 1, len(y))
-		peak = diff_curve[np.argmax(diff_curve)]
-		threshold = peak - (self.S / (len(y) - 1))
-		return bool(peak > threshold and diff_curve[-1] < threshold)
+		x = np.asarray(est.values, dtype=float).reshape(-1)
+		scaled = x / np.arange(1, x.size + 1)
+		path = np.add.accumulate(np.abs(scaled[1:] - scaled[:-1]))  # non-decreasing: first point is its minimum, last its maximum
+		m, span = path.size, path[-1] - path[0]
+		if not (span > 0 and self.S > 0):
+			return False  # flat path (or no sensitivity): no knee to find
+		bulge = (path - path[0]) / span - np.arange(m) / (m - 1)
+		return bool(bulge.max() - bulge[-1] > self.S / (m - 1))
 
 	def message(self, est) -> str:
 		return f"Est: {_summary(est.estimate)} (#S:{ len(est) }, S={self.S:3f})"

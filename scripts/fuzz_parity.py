@@ -61,7 +61,7 @@ while time.time() - t0 < budget:
 	P = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 128, 129, 200, 257]))
 	if TILES:
 		P = int(rng.choice([17, 20, 32, 33, 40, 64, 65, 128, 129, 200, 257])) if dtype == np.float64 else int(rng.choice([33, 40, 64, 65, 100, 128, 129, 256, 257, 300]))
-	deg = int(rng.integers(1, min(n, 20 if TILES else 40) + 1))
+	deg = int(rng.integers(1, min(n, (150 if rng.random() < 0.25 else 20) if TILES else 40) + 1))  # (tiles: a quarter of the cases run long recurrences, r04)
 	orth = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, deg]))
 	fun, kw = [("log", {}), ("exp", {"t": -0.1}), ("identity", {}), ("sqrt", {}), ("inv", {})][int(rng.integers(0, 5))]
 	Ad = A.astype(dtype)

@@ -1,0 +1,111 @@
+// Where do the full-reorthogonalisation sweeps lose their 20 %? scripts/microbench_multistream.hip
+// reads 17 zero-filled 1-GB panels at 7.0-7.2 TB/s; k_reorth_dot / k_reorth_update (the same access shape) run at 5.5.
+// This walks from the one to the other one factor at a time, on the production kernels' own code:
+//   A  k_multi<17> (the microbenchmark's loop) on 17 x 1.024 GB, zeros                        - the 7 TB/s shape
+//   B  k_multi<17> on the plan's ring: 31 slots x 2 panels x 1.024 GB (63.5 GB), columns at ring slots, grid.y = 2
+//   C  B on non-zero data
+//   D  k_reorth_dot<double, 64> itself (rc = 16; later chunk / first chunk with the axpy + store), zeros and non-zero data
+//   E  k_reorth_update<double, 64> itself (r = 16)
+//   F  D/E at other residencies
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/mbr scripts/microbench_reorth.hip ; run: /tmp/mbr
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include "../primate_amd/csrc/slq_kernels.hpp"
+using namespace slq;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int K, int NT>
+__global__ __launch_bounds__(512) void k_multi(const d2 *base, int64_t col_vecs, int64_t panel_vecs, int nrows, int S, int j, double *sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  d2 acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) acc[i] = (d2)0.0;
+  const int stride = gridDim.x * 8;
+  const d2 *pb = base + blockIdx.y * panel_vecs;
+  for (int row = blockIdx.x * 8 + wave; row < nrows; row += stride) {
+    const int64_t ro = (int64_t)row * 64 + lane;
+    d2 u[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const d2 *p = pb + (int64_t)ring_slot(j - i, S) * col_vecs + ro;
+      u[i] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] += u[i] * u[0];
+  }
+  d2 s = (d2)0.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) s += acc[i];
+  if (s[0] + s[1] == 1.2345e-300) sink[0] = s[0];
+}
+
+__global__ void k_fill(double *p, size_t nel) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nel; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long h = i * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    p[i] = (double)(h & 0xFFFFF) * 1e-6 - 0.5;
+  }
+}
+
+template <typename Fn> static double timeit(Fn fn, int reps) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  fn();
+  CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) fn(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); CK(hipGetLastError()); return ms / reps;
+}
+
+int main(int argc, char **argv) {
+  const bool brief = argc > 1;  // any argument: the in-place sweeps at the production residency only (A/B of store flavours)
+  const int n = 1000000, NP = 2, PW = 128, bpad = 256, S = 31;
+  const size_t slot = (size_t)NP * n * PW;  // elements per ring slot (both panels)
+  double *ring, *sink, *coef, *part;
+  CK(hipMalloc(&ring, S * slot * 8)); CK(hipMemset(ring, 0, S * slot * 8));
+  CK(hipMalloc(&sink, 8)); CK(hipMalloc(&coef, 64 * bpad * 8)); CK(hipMemset(coef, 0, 64 * bpad * 8));
+  CK(hipMalloc(&part, (size_t)17 * 2048 * bpad * 8));
+  CK(hipFuncSetAttribute((const void *)k_reorth_update<double, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const double GB17 = 17.0 * n * 1024.0 / 1e9;
+  for (int data = 0; data < (brief ? 1 : 2); ++data) {
+    if (data) { k_fill<<<4096, 256>>>(ring, S * slot); CK(hipDeviceSynchronize()); }
+    printf("---- data: %s\n", data ? "non-zero" : "zeros");
+    for (int blocks : {256, 512}) {
+      if (brief) break;
+      // A: 17 contiguous 1.024-GB panels (S = 17 slots of ONE panel each, j = 16: slots 16..0), one panel's worth of rows per launch
+      double t = timeit([&] { k_multi<17, 1><<<dim3(blocks, 1), 512>>>((const d2 *)ring, (int64_t)n * 64, 0, n, 17, 16, sink); }, 5);
+      printf("A  k_multi<17,nt>  17 x 1.024 GB contiguous     blocks=%4d        %.3f ms  %.0f GB/s\n", blocks, t, GB17 / t * 1e3);
+      t = timeit([&] { k_multi<17, 0><<<dim3(blocks, 1), 512>>>((const d2 *)ring, (int64_t)n * 64, 0, n, 17, 16, sink); }, 5);
+      printf("A  k_multi<17>     17 x 1.024 GB contiguous     blocks=%4d        %.3f ms  %.0f GB/s\n", blocks, t, GB17 / t * 1e3);
+    }
+    for (int blocks : {128, 256, 512}) {
+      if (brief) break;
+      double t = timeit([&] { k_multi<17, 1><<<dim3(blocks, 2), 512>>>((const d2 *)ring, (int64_t)slot / 2, (int64_t)n * 64, n, S, 40, sink); }, 5);
+      printf("B  k_multi<17,nt>  ring of 31 slots, 2 panels   blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * GB17 / t * 1e3);
+      t = timeit([&] { k_multi<17, 0><<<dim3(blocks, 2), 512>>>((const d2 *)ring, (int64_t)slot / 2, (int64_t)n * 64, n, S, 40, sink); }, 5);
+      printf("B  k_multi<17>     ring of 31 slots, 2 panels   blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * GB17 / t * 1e3);
+    }
+    for (int blocks : {128, 256, 512}) {
+      if (brief && blocks != 256) continue;
+      // D: the production dots sweep. later chunk: reads w + 16 columns; first chunk: + W_c read, w stored
+      double t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 16, 14, 0, coef, part, bpad); }, 5);
+      printf("D  k_reorth_dot    later chunk rc=14 (15 reads)  blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 15.0 * n * 1024 / 1e9 / t * 1e3);
+      t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 16, 16, 0, coef, part, bpad); }, 5);
+      printf("D  k_reorth_dot    later chunk rc=16 (17 reads)  blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * GB17 / t * 1e3);
+      t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 0, 16, 1, coef, part, bpad); }, 5);
+      printf("D  k_reorth_dot    first chunk rc=16 (17R + 1W)  blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
+      const size_t lds = sizeof(double) * kWaves * 64 * 2 + (size_t)16 * PW * 8;
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, coef, part, bpad, nullptr); }, 5);
+      printf("E  k_reorth_update r=16 (17R + 1W)               blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
+      t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 0, 16, 2, coef, part, bpad); }, 5);
+      printf("D' k_reorth_dot    first chunk, axpy deferred (17R) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 17.0 * n * 1024 / 1e9 / t * 1e3);
+      t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 16, 14, 2, coef, part, bpad); }, 5);
+      printf("D' k_reorth_dot    later chunk rc=14, deferred (16R) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 16.0 * n * 1024 / 1e9 / t * 1e3);
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, coef, part, bpad, coef); }, 5);
+      printf("E' k_reorth_update r=16 + deferred axpy (17R + 1W) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
+      const size_t lds30 = sizeof(double) * kWaves * 64 * 2 + (size_t)30 * PW * 8;
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds30>>>(n, ring, (int64_t)slot, S, 40, 0, 30, coef, part, bpad, nullptr); }, 3);
+      printf("E  k_reorth_update r=30 (31R + 1W)               blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 32.0 * n * 1024 / 1e9 / t * 1e3);
+    }
+  }
+  return 0;
+}

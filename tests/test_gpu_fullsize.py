@@ -76,9 +76,11 @@ def test_config4_heat_kernel_diag_fp32_full_size(eng, oracle):
 	assert abs(q.mean() - exact.sum()) < 6 * q.std(ddof=1) / np.sqrt(P)
 
 
-def test_config3_estrada_index_full_size(eng):
-	"""configs[2]: tr exp(A) of a G(n, 16/n) graph, n = 5e5, k = 40: quadrature and action agree, and the
-	reorthogonalisation depth does not move the quadrature."""
+def test_config3_estrada_index_full_size(eng, oracle):
+	"""configs[2]: tr exp(A) of a G(n, 16/n) graph, n = 5e5, k = 40: the oracle at full size on two columns of the quadrature at
+	orth 0 and 3 (the operator's gathers are not cache-served: orth 3 must run the stored-u sequence) and on one column of the
+	action exp(A)v; quadrature and action agree, and the reorthogonalisation depth does not move the quadrature
+	(src/primate/trace.py:233-315 is the driver these feed)."""
 	n, k, P = 500000, 40, 32
 	rng = np.random.default_rng(1234)
 	mm = int(n * 16 / 2)
@@ -92,11 +94,16 @@ def test_config3_estrada_index_full_size(eng):
 	qs = {}
 	for orth in (0, 3, k):
 		plan = eng.LanczosPlan(op, P, k, orth)
+		if orth == 3:
+			assert plan.describe()["sequence"] == "fused_stored_u", plan.describe()
 		plan.generate_probes("rademacher", seed=1234)
+		Vo = np.asfortranarray(plan.get_probes()[:, [0, P - 1]])
 		plan.run()
 		qs[orth] = plan.quadrature("exp")
 		a, b, steps = plan.tridiag()
 		assert np.all(steps == k)
+		if orth in (0, 3):  # the oracle on the first and last probe, full size (0.2 s per probe)
+			np.testing.assert_allclose(qs[orth][[0, P - 1]], oracle.quad_batch(W, Vo, k, orth, fun="exp", fresh_q=True, prefer="csr"), rtol=1e-10, err_msg=f"orth={orth}")
 		np.testing.assert_allclose(a[:, 0] * n, eng_quad_identity(plan, op, P, k, orth), rtol=1e-10)
 		plan.close()
 	np.testing.assert_allclose(qs[3], qs[0], rtol=1e-8)
@@ -107,6 +114,15 @@ def test_config3_estrada_index_full_size(eng):
 	plan.run()
 	Y = plan.fun_action("exp")
 	np.testing.assert_allclose(np.einsum("ij,ij->j", V, Y), qs[3][:16], rtol=1e-8)  # v^T (f(A) v) == quadrature
+	## the action itself against the oracle's recurrence with the whole basis kept: ||v|| Q Y (f(theta) * Y[0, :])
+	## (MatrixFunction._matvec, src/primate/operators.py:113-124), last column
+	al, be, Q = np.zeros(k + 1), np.zeros(k + 1), np.zeros((n, k), order="F")
+	v = np.ascontiguousarray(V[:, 15])
+	assert oracle.lanczos(W, v.copy(), k, 1e-8, 3, al, be, Q) == k
+	th, Yv = np.linalg.eigh(np.diag(al[:k]) + np.diag(be[1:k], 1) + np.diag(be[1:k], -1))
+	ref_y = np.linalg.norm(v) * (Q @ (Yv @ (np.exp(th) * Yv[0, :])))
+	np.testing.assert_allclose(Y[:, 15], ref_y, rtol=0, atol=1e-9 * np.abs(ref_y).max())
+	del Q
 	Y1 = plan.fun_action("identity")
 	np.testing.assert_allclose(Y1, W @ V, rtol=1e-9, atol=1e-9)  # A v is in the Krylov space: exact
 

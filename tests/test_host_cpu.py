@@ -313,3 +313,31 @@ def test_bench_starts_its_own_ranks(capfd):
 	rc = bench.spawn_ranks(2, [], cmd=[sys.executable, "-c", hang], timeout=3)
 	out, err = capfd.readouterr()
 	assert rc != 0 and out == "{up 0\n"
+	## a rank that DIES while rank 0 is blocked (in a collective, on the real thing): the parent must not sit in rank 0's
+	## pipe until a watchdog fires - it ends rank 0 and reports the failure at once
+	import time
+
+	die = "import os, sys, time; r = int(os.environ['RANK']); print('{up', r, flush=True); time.sleep(600) if r == 0 else sys.exit(7)"
+	t0 = time.monotonic()
+	rc = bench.spawn_ranks(2, [], cmd=[sys.executable, "-c", die], timeout=300)
+	out, err = capfd.readouterr()
+	assert rc != 0 and time.monotonic() - t0 < 60 and "exit codes" in err
+
+
+def test_bench_strong_scaling_shards():
+	"""`bench.py --scaling strong`: --probes is the global batch of a step and rank r advances shard_range(P, r, N) of it
+	(the reduction the shards feed: src/primate/stats.py:77-86). The bench's split is the library's, covers
+	every probe id once, and 256 probes over 8 GPUs are the 32-probe panels hutch() itself draws (src/primate/trace.py:36)."""
+	import bench
+	from primate_amd.distributed import shard_range
+
+	for P, N in ((256, 8), (256, 3), (7, 8), (512, 4)):
+		blocks = [bench.shard_range(P, r, N) for r in range(N)]
+		assert blocks == [shard_range(P, r, N) for r in range(N)]
+		assert blocks[0][0] == 0 and blocks[-1][1] == P and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+	assert bench.shard_range(256, 5, 8) == (160, 192)
+	## argument plumbing: the flag exists, defaults to weak, and the launcher passes it on untouched
+	import subprocess
+
+	h = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True).stdout
+	assert "--scaling" in h and "strong" in h and "--timeout" in h
