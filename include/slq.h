@@ -168,6 +168,7 @@ typedef struct {
   int upper_alpha;   /* alpha pass walks the upper triangle (exactly symmetric CSR)                     */
   double far_per_row;/* stored nonzeros per row further than 4096 rows from the diagonal                */
   int tiles;         /* fused passes run on LDS workgroup tiles: 0 no, 1 behind barriers, 2 ring-fed (SLQ_TILES) */
+  int fused_alpha;   /* sequence 4 only: the update pass of step j also takes step j + 1's alpha dot (no alpha-only pass after step 0) */
 } slq_plan_info;
 int slq_plan_describe(const slq_plan *plan, slq_plan_info *out);
 

@@ -110,7 +110,7 @@ class PlanInfo(C.Structure):
 	"""slq_plan_info (include/slq.h)."""
 
 	_fields_ = [("panel_width", C.c_int), ("panels", C.c_int), ("ring_slots", C.c_int), ("sequence", C.c_int), ("pipelined", C.c_int),
-				("reordered", C.c_int), ("upper_alpha", C.c_int), ("far_per_row", C.c_double), ("tiles", C.c_int)]  # fmt: skip
+				("reordered", C.c_int), ("upper_alpha", C.c_int), ("far_per_row", C.c_double), ("tiles", C.c_int), ("fused_alpha", C.c_int)]  # fmt: skip
 
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <system_error>
@@ -126,6 +127,17 @@ struct slq_operator {
     bool tried = false;
   } merged[2];
   std::mutex *merged_lock = nullptr;
+  // the update pass with the next step's alpha dot fused in (slq_ring_fa.hpp; built the first time a plan asks: ensure_fa_stream):
+  // the upper-triangle stream WITHOUT the entries that cross from one XCD chunk into the next, and those entries as a list
+  // (row, column, doubled value) for k_alpha_edges
+  struct FaStream {
+    int32_t *desc = nullptr;
+    char *rec = nullptr;
+    int32_t *er = nullptr, *ec = nullptr;
+    void *ev = nullptr;
+    int nedges = 0;
+    bool tried = false;
+  } fa;
   // exactly symmetric CSR only: upper triangle (diagonal + 2x strict upper) for the alpha pass, whose
   // q^T A q = sum_i q_i (a_ii q_i + 2 sum_{j>i} a_ij q_j) then gathers half the panel rows (null: none)
   int32_t *rowptr_u = nullptr, *colind_u = nullptr;
@@ -168,10 +180,11 @@ struct Switches {
   int ring32;      // SLQ_RING32    opt-in: finished Lanczos vectors archived as fp32 for deep reorthogonalisation
   int fused_pad;   // SLQ_FUSED_LDS_PAD (-1: by row loop)
   int spmm_pad;    // SLQ_SPMM_LDS_PAD
+  int fused_alpha; // SLQ_FUSED_ALPHA the ring-fed update pass of wide panels also takes the next step's alpha dot (slq_ring_fa.hpp; r04)
   int defer_axpy;  // SLQ_DEFER_AXPY the block-CGS sweeps apply `w -= cB W_c` in the update sweep: the dots sweeps are read-only (r04; 0: first chunk stores)
   unsigned key() const {
     unsigned k = 0;
-    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, dense_lds, pipe, ring32, fused_pad, spmm_pad, defer_axpy})
+    for (int v : {fused, nt, graph, mgs, stored_u, merged, cross, tiles, ring_alpha, ring_rev, dense_mfma, dense_tile16, dense_lds, pipe, ring32, fused_pad, spmm_pad, fused_alpha, defer_axpy})
       k = k * 1000003u + (unsigned)(v + 7);
     return k;
   }
@@ -228,12 +241,23 @@ struct slq_plan {
   bool rs_u_padded;            // ... whose rows are padded to whole chunks of four entries (the alpha-only pass's branch-free consumer)
   int32_t rs_xcd[9];
   bool ring_staged;           // the alpha-only pass's loaders go through registers (SLQ_RING_STAGED; slq_ring.hpp: GEO 1)
+  // the update pass takes the next step's alpha dot a fixed lag of tile rounds behind its write front (slq_ring_fa.hpp; SLQ_FUSED_ALPHA):
+  bool fa_on = false;
+  int *fa_cnt = nullptr;      // chunk counters [NP][8][fa_rounds] + the XCC table [8], zeroed at the start of every run
+  int fa_rounds = 0;
+  int part_maxblk = 0;        // blocks per slab of `part`
 };
 
 // SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
 // loader waves (k_csr_ring_pass). Read when an operator is created (the rows are regrouped into the tiles) and when a plan
 // is created (whether its passes use them).
 constexpr int kTilesDefault = 2;
+// Opt-in (SLQ_FUSED_ALPHA=1). Built and parity-green in r04, and slower than the two passes it replaces: configs[1], 256 probes, orth 3: 2.5 ms per step even
+// WITHOUT its counter polls (racy) against 1.36 + 0.40 ms; 5.9 ms with them (DESIGN.md §4.7 has the break-down and what it says about the ring).
+constexpr int kFusedAlphaDefault = 0;
+// set when a fused update + alpha pass found two XCDs behind one value of blockIdx.x % 8 (slq_ring_fa.hpp): later plans keep the
+// separate alpha-only pass
+static std::atomic<bool> g_fa_broken{false};
 constexpr double kTileMaxColsPerRow = 4.5;      // tiles are kept when a tile row needs at most this many distinct panel rows
 constexpr double kTileAlphaColsPerRow = 2.6;    // upper-triangle tiles: the alpha-only pass takes the ring up to this many landed rows per row (r03: 7-point grids too)
 constexpr double kTileAlphaMergedColsPerRow = 2.6;  // ... and on the merged tiles of narrow panels up to this many (of the unmerged tiles)
@@ -1609,6 +1633,8 @@ extern "C" int slq_operator_destroy(slq_operator *op) {
   if (op->tile_rec) hipFree(op->tile_rec);
   if (op->tile_desc_u) hipFree(op->tile_desc_u);
   if (op->tile_rec_u) hipFree(op->tile_rec_u);
+  for (void *q : {(void *)op->fa.desc, (void *)op->fa.rec, (void *)op->fa.er, (void *)op->fa.ec, op->fa.ev})
+    if (q) hipFree(q);
   for (auto &m : op->merged) {
     if (m.desc) hipFree(m.desc);
     if (m.rec) hipFree(m.rec);
@@ -1686,6 +1712,86 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
         *q = nullptr;
       }
     }
+    return ok;
+  } catch (const std::bad_alloc &) {
+    return false;
+  }
+}
+
+// The interior upper-triangle stream of the fused update + alpha pass (slq_ring_fa.hpp): the operator's upper triangle (diagonal +
+// doubled strict upper entries, as the alpha-only pass reads it) over the SAME tiles, minus every entry whose column lies in a
+// later XCD chunk than its row - those rows of W_{j+1} are written by another XCD, whose L2 this one cannot see inside a launch -
+// and those entries as an edge list. Rows padded to whole chunks of four entries (the branch-free consumer); given up when some
+// tile's padded record would outgrow its slot. Built from what the operator keeps on the device, once.
+static bool ensure_fa_stream(slq_operator *op) {
+  if (!op->tile_desc || !op->tiles_ringed || !op->merged_lock || !op->rowptr_u || !op->tile_desc_u) return false;
+  std::lock_guard<std::mutex> guard(*op->merged_lock);
+  slq_operator::FaStream &f = op->fa;
+  if (f.tried) return f.desc != nullptr;
+  f.tried = true;
+  const int64_t n = op->n;
+  const size_t nu = (size_t)op->nnz_u, es = esize(op->dtype);
+  const int32_t ntiles = op->tiles.xcd_tile[8];
+  try {
+    std::vector<int32_t> urp((size_t)n + 1), uci(nu), tr((size_t)ntiles + 1);
+    std::vector<char> uva(nu * es);
+    if (hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(tr.data(), op->tiles.tile_row, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    // chunk of every row: rows [tr[xcd_tile[x]], tr[xcd_tile[x + 1]]) belong to XCD x
+    int32_t cend[8];
+    for (int x = 0; x < 8; ++x) cend[x] = tr[(size_t)op->tiles.xcd_tile[x + 1]];
+    std::vector<int32_t> irp((size_t)n + 1, 0), ici, er, ec;
+    std::vector<char> iva, ev;
+    ici.reserve(nu + kCsrPad);
+    iva.reserve((nu + kCsrPad) * es);
+    int x = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      while (x < 7 && r >= cend[x]) ++x;
+      for (int32_t q = urp[(size_t)r]; q < urp[(size_t)r + 1]; ++q) {
+        const int32_t c = uci[(size_t)q];
+        if (c >= cend[x]) {  // crosses into a later chunk
+          er.push_back((int32_t)r);
+          ec.push_back(c);
+          ev.insert(ev.end(), uva.begin() + (size_t)q * es, uva.begin() + ((size_t)q + 1) * es);
+        } else {
+          ici.push_back(c);
+          iva.insert(iva.end(), uva.begin() + (size_t)q * es, uva.begin() + ((size_t)q + 1) * es);
+        }
+      }
+      irp[(size_t)r + 1] = (int32_t)ici.size();
+    }
+    ici.resize(ici.size() + kCsrPad, 0);
+    iva.resize(iva.size() + (size_t)kCsrPad * es, 0);
+    std::vector<int32_t> tp, tc, lc, si;
+    RawBuf<int32_t> desc;
+    RawBuf<char> rec;
+    int mx = 0;
+    build_tile_meta(n, irp.data(), ici.data(), tr, tp, tc, lc, si, &mx);
+    if (mx > kRingTileCols) return false;
+    bool pad = true;
+    if (op->dtype == SLQ_F64) build_ring_stream<double>(1, irp.data(), (const double *)iva.data(), tr, tp, tc, lc, si, desc, rec, &pad);
+    else build_ring_stream<float>(1, irp.data(), (const float *)iva.data(), tr, tp, tc, lc, si, desc, rec, &pad);
+    if (!pad) return false;
+    const size_t ne = er.size();
+    bool ok = hipMalloc((void **)&f.desc, desc.size() * 4) == hipSuccess && hipMalloc((void **)&f.rec, rec.size()) == hipSuccess &&
+              hipMalloc((void **)&f.er, std::max<size_t>(ne, 1) * 4) == hipSuccess && hipMalloc((void **)&f.ec, std::max<size_t>(ne, 1) * 4) == hipSuccess &&
+              hipMalloc(&f.ev, std::max<size_t>(ne, 1) * es) == hipSuccess;
+    ok = ok && hipMemcpy(f.desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(f.rec, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && ne) {
+      ok = hipMemcpy(f.er, er.data(), ne * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(f.ec, ec.data(), ne * 4, hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy(f.ev, ev.data(), ne * es, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    f.nedges = (int)ne;
+    if (!ok) {
+      for (void **q : {(void **)&f.desc, (void **)&f.rec, (void **)&f.er, (void **)&f.ec, &f.ev}) {
+        if (*q) hipFree(*q);
+        *q = nullptr;
+      }
+    }
+    if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] fused alpha: interior upper stream built, %zu entries cross XCD chunks (of %zu)\n", ne, nu);
     return ok;
   } catch (const std::bad_alloc &) {
     return false;
@@ -1888,6 +1994,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   if (p->stage) hipFree(p->stage);
   if (p->scal) hipFree(p->scal);
   if (p->part) hipFree(p->part);
+  if (p->fa_cnt) hipFree(p->fa_cnt);
   if (p->quad_d) hipFree(p->quad_d);
   if (p->st.active) hipFree(p->st.active);
   ctx_release(p->ctx);
@@ -1921,7 +2028,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   p->sw = Switches{env_int("SLQ_FUSED", 1), env_int("SLQ_NT", 1) != 0, env_int("SLQ_GRAPH", 1) != 0, env_int("SLQ_MGS", 0) != 0,
                    env_int("SLQ_STORED_U", 1) != 0, env_int("SLQ_MERGED", 1) != 0, env_int("SLQ_CROSS", 1) != 0,
                    tiles_mode() != 0, env_int("SLQ_RING_ALPHA", 2), env_int("SLQ_RING_REV", 1) != 0, env_int("SLQ_DENSE_MFMA", 1) != 0, env_int("SLQ_DENSE_TILE16", 0) != 0, env_int("SLQ_DENSE_LDS", 1) != 0, env_int("SLQ_PIPE", -1), env_int("SLQ_RING32", 0) != 0,
-                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344), env_int("SLQ_DEFER_AXPY", 1) != 0};
+                   env_int("SLQ_FUSED_LDS_PAD", -1), env_int("SLQ_SPMM_LDS_PAD", 57344), env_int("SLQ_FUSED_ALPHA", kFusedAlphaDefault) != 0,
+                   env_int("SLQ_DEFER_AXPY", 1) != 0};
   choose_geometry(op->dtype, nprobes, &p->LPR, &p->PW, &p->NP);
   p->bpad = p->NP * p->PW;
   p->S = ring_slots(deg, orth, p->keep_basis);
@@ -2000,6 +2108,10 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
       p->ring_staged = env_int("SLQ_RING_STAGED", 0) != 0;
       // the Gram sequence needs every step of the window on k_ring_pass (PASS_UPDATEG), i.e. the deep form too
       p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && env_int("SLQ_GRAM", 1) != 0;
+      // fused alpha: whole-row panels on the Gram sequence with at most kRingMaxR ring columns per step, descending update sweeps,
+      // the alpha-only pass on the padded upper-triangle stream (step 0 still runs it), and the interior stream buildable
+      p->fa_on = p->sw.fused_alpha && !g_fa_broken.load() && p->gram && p->ringR == 1 && p->sw.ring_rev && p->rs_desc_u != nullptr && p->rs_u_padded &&
+                 p->sw.ring_alpha == 2 && orth >= 1 && orth <= kRingMaxR && ensure_fa_stream(op);
     }
   }
   {
@@ -2023,12 +2135,19 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   const size_t bp = p->bpad;
   // alpha[deg+1], nu[orth margin for stale vectors t < 0 | deg+1], vnorm2, coefA[2], coefB, cross, gram[2][kFusedMaxR+1], gamma[rmax]
   const size_t nscal = ((size_t)(deg + 1) * 2 + (size_t)orth + 1 + 2 + 1 + 1 + 2 * (kFusedMaxR + 1) + (size_t)p->rmax) * bp;
-  const size_t npart = (size_t)kReorthChunk * std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT) * bp;
+  p->part_maxblk = std::max(std::max(std::max(std::max(p->nblkA, p->nblkF), p->nblkU), p->nblkS), p->nblkT);
+  const size_t npart = (size_t)kReorthChunk * p->part_maxblk * bp;
+  if (p->fa_on) {
+    int mxt = 1;
+    for (int x = 0; x < 8; ++x) mxt = std::max(mxt, p->rs_xcd[x + 1] - p->rs_xcd[x]);
+    p->fa_rounds = (mxt + p->nblkT / 8 - 1) / (p->nblkT / 8) + 2;
+  }
   hipError_t e = hipMalloc(&p->ring, ring_bytes);
   const size_t ring32_bytes = p->ring32_on ? (size_t)p->S32 * (size_t)p->slot_stride * sizeof(float) : 0;
   if (e == hipSuccess && p->ring32_on) e = hipMalloc((void **)&p->ring32, ring32_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
+  if (e == hipSuccess && p->fa_on) e = hipMalloc((void **)&p->fa_cnt, ((size_t)p->NP * 8 * p->fa_rounds + 8) * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void **)&p->st.active, bp * 2 * sizeof(int) + 16);
   if (e == hipSuccess) e = hipMalloc((void **)&p->quad_d, (bp + 2 * bp * (size_t)deg) * 8);
   // dense fp64 operator on the matrix cores with 32-row tiles: n/32 workgroups per panel rarely fill 256 CUs, so K is
@@ -2269,6 +2388,11 @@ static bool plan_tiled(const slq_plan *p) { return p->ringR > 0; }
 // it through slq_debug_ring_flag_status); check_ring_flag() reads the device word behind whatever the caller has enqueued
 // and is called by EVERY accessor that hands results of a run to the host.
 static int ring_flag_status(int flag) {
+  if (flag == 2) {
+    g_fa_broken.store(true);
+    return fail(SLQ_EHIP, "the fused update + alpha pass found workgroups of one XCD slot on two XCDs (its hand-offs go through one XCD's L2): results are "
+                          "invalid; plans created from now on use the separate alpha pass (SLQ_FUSED_ALPHA=0)");
+  }
   if (flag) return fail(SLQ_EHIP, "the ring-fed tile pass gave up waiting on a tile (SLQ_TILES=2): results are invalid");
   return SLQ_OK;
 }
@@ -2308,6 +2432,7 @@ extern "C" int slq_plan_describe(const slq_plan *p, slq_plan_info *out) {
   out->upper_alpha = p->op->rowptr_u ? 1 : 0;
   out->far_per_row = p->op->far_per_row;
   out->tiles = plan_tiled(p) ? (p->op->tiles_ringed ? 2 : 1) : 0;
+  out->fused_alpha = (p->fa_on && plan_sequence(p) == 4) ? 1 : 0;
   return SLQ_OK;
 }
 
@@ -2739,6 +2864,50 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   return SLQ_OK;
 }
 
+// alpha's share of the upper-triangle entries that cross XCD chunks (k_alpha_edges), after a fused update + alpha pass
+template <typename F, int L> static inline void launch_alpha_edges(slq_plan *p, int nblk_e, hipStream_t st, int slot, double *part_e) {
+  if constexpr (L == 64) {
+    const slq_operator *op = p->op;
+    k_alpha_edges<F, L><<<dim3(nblk_e, p->NP), dim3(kBlock), 0, st>>>(p->n, op->fa.nedges, op->fa.er, op->fa.ec, (const F *)op->fa.ev, (const F *)slot_ptr(p, slot), part_e,
+                                                                      p->bpad);
+  }
+}
+
+// the ring-fed update pass of step j with step j + 1's alpha dot fused in (slq_ring_fa.hpp); gen: its number within the run
+static int launch_ring_fa(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t st, int j, int gen) {
+  RingArgs a;
+  a.pass = pass;
+  a.rc = rc;
+  a.staged = 0;
+  a.grid = grid;
+  a.st = st;
+  a.n = p->n;
+  a.desc = p->rs_desc;
+  a.rec = p->rs_rec;
+  a.desc_a = p->op->fa.desc;
+  a.rec_a = p->op->fa.rec;
+  for (int x = 0; x < 9; ++x) a.xr.first[x] = p->rs_xcd[x];
+  a.ring = p->ring;
+  a.slot_stride = p->slot_stride;
+  a.S = p->S;
+  a.j = j;
+  a.coefA = p->st.coefA;
+  a.coefB = p->st.coefB;
+  a.gamma = p->st.gamma;
+  a.part = p->part;
+  a.bpad = p->bpad;
+  a.xt = env_int("SLQ_FA_MODE", 0);  // (timing experiments only: 1 skips the counter poll, 2 the alpha items)
+  a.fail = p->ring_fail_d;
+  a.dbg = nullptr;
+  a.cnt = p->fa_cnt;
+  a.cnt_rounds = p->fa_rounds;
+  a.gen = gen;
+  a.xcc_tab = p->fa_cnt + (size_t)p->NP * 8 * p->fa_rounds;
+  const int rc_l = p->dtype == SLQ_F64 ? slq_ring_fa_launch_f64_l64(a) : slq_ring_fa_launch_f32_l64(a);
+  if (rc_l != 0) return fail(SLQ_EINVAL, "no fused update + alpha kernel for pass %d with %d ring columns", pass, rc);
+  return SLQ_OK;
+}
+
 // enqueue the deg-step launch sequence on the context stream (also run under stream capture)
 static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   if (p->ring32_on && p->nstale > 0) return fail(SLQ_EINVAL, "SLQ_RING32 does not combine with preloaded stale ring columns");
@@ -2752,6 +2921,9 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   // alpha and nu[1..] start from zero (the reference's fresh np.zeros buffers, lanczos.py:101-102)
   HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
+  if (p->fa_on) HIP_TRY(hipMemsetAsync(p->fa_cnt, 0, ((size_t)p->NP * 8 * p->fa_rounds + 8) * sizeof(int), st));
+  int fa_gen = 0;         // fused update + alpha passes launched so far in this run (their counters' generation)
+  int fa_alpha_slab = -1; // >= 0: step j's alpha dot was taken by step j - 1's update pass and lies in this slab of `part` (raw: not yet / nu^2)
   const dim3 gA(p->nblkA, p->NP), gS(p->nblkS, p->NP), gU(p->nblkU, p->NP), gF((bp + 63) / 64);
   const dim3 gAf(p->nblkF, p->NP);
   const dim3 gT(p->nblkT, p->NP);
@@ -2843,15 +3015,39 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       const bool gram = gen && p->gram && r >= 1 && p->nstale == 0;
       if (gram) {
         const int xa = j > 0 ? 1 : 0;  // (alpha_j's -beta q_j.q_{j-1} part is a Gram entry: the pass leaves W_p unread)
-        PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xa); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xa); });
-        PROFILED(p, SLQ_K_FINALIZE,
-                 hipLaunchKernelGGL(k_fin_gram, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, alpha_tiled ? p->nblkT : p->nblkF, j, r, orth_tol));
-        PROFILED(p, SLQ_K_REORTH_UPD, SLQ_TRY(launch_ring_gen(p, PASS_UPDATEG, r, gT, st, j, 0)));
+        const size_t slab = (size_t)p->part_maxblk * bp;  // (the edge kernel's partials live in slab 12 of `part`, away from every pass's own)
+        double *part_e = p->part + 12 * slab;
+        const int nblk_e = std::max(1, std::min(p->part_maxblk, (op->fa.nedges + kWaves - 1) / kWaves));
+        if (fa_alpha_slab < 0) {
+          PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xa); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xa); });
+          PROFILED(p, SLQ_K_FINALIZE,
+                   hipLaunchKernelGGL(k_fin_gram, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, alpha_tiled ? p->nblkT : p->nblkF, j, r, orth_tol,
+                                      (const double *)nullptr, 0, 0));
+        } else {
+          // alpha_j's dot came out of step j - 1's update pass (slq_ring_fa.hpp) and the edge kernel: raw sums, normalised here
+          PROFILED(p, SLQ_K_FINALIZE,
+                   hipLaunchKernelGGL(k_fin_gram, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part + (size_t)fa_alpha_slab * p->nblkT * bp, p->nblkT, j, r,
+                                      orth_tol, (const double *)part_e, op->fa.nedges > 0 ? nblk_e : 0, 1));
+        }
+        // the next step's alpha dot rides on this update pass when that step is a Gram step of at most kRingMaxR columns too
+        const int r_next = std::min(j + 2 + p->nstale, p->orth);
+        const bool fa = p->fa_on && j + 1 < deg && r <= kRingMaxR && r_next <= kRingMaxR;
+        if (fa) {
+          PROFILED(p, SLQ_K_REORTH_UPD, SLQ_TRY(launch_ring_fa(p, PASS_UPDATEG, r, gT, st, j, ++fa_gen)));
+          if (op->fa.nedges > 0)
+            PROFILED(p, SLQ_K_SPMM,
+                     DISPATCH(p->dtype, 64, (launch_alpha_edges<F, L>(p, nblk_e, st, sn_, part_e))));
+          fa_alpha_slab = 1 + r;
+        } else {
+          PROFILED(p, SLQ_K_REORTH_UPD, SLQ_TRY(launch_ring_gen(p, PASS_UPDATEG, r, gT, st, j, 0)));
+          fa_alpha_slab = -1;
+        }
         PROFILED(p, SLQ_K_FINALIZE,
                  hipLaunchKernelGGL(k_fin_beta_gram, dim3((bp + 63) / 64, r + 1), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkT, j, r, residual_tol));
         prev_xt = false;
         continue;
       }
+      fa_alpha_slab = -1;
       if (merged) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,

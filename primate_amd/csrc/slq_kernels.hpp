@@ -2059,11 +2059,16 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_adots(StepState st, const d
 // 2-8 columns behind a three-term step only ever removes rounding-level components, most of them below the
 // reference's own threshold (lanczos.h:53,62).
 // k_fin_gram: blockIdx.y = i as in k_fin_adots. part: alpha partials of the alpha-only pass.
-__global__ __launch_bounds__(kFinThreads) void k_fin_gram(StepState st, const double *__restrict__ part, int nblk, int j, int RC, double orth_tol) {
+// part2 / nblk2 (may be 0) / raw: the alpha dot taken by the previous step's fused update pass (slq_ring_fa.hpp) and the edge kernel's share of it
+// (k_alpha_edges) - raw sums W_j . (A W_j), normalised here by 1 / nu_j^2 (= coefA^2) instead of term by term.
+__global__ __launch_bounds__(kFinThreads) void k_fin_gram(StepState st, const double *__restrict__ part, int nblk, int j, int RC, double orth_tol,
+                                                          const double *__restrict__ part2, int nblk2, int raw) {
   __shared__ double red4[kFinThreads];
   const int i = blockIdx.y;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const double a_raw = sum_partials(part, nblk, st.bpad, col, red4);
+  double a_raw = sum_partials(part, nblk, st.bpad, col, red4);
+  if (nblk2 > 0) a_raw += sum_partials(part2, nblk2, st.bpad, col, red4);
+  if (raw && col < st.bpad) a_raw *= st.coefA[col] * st.coefA[col];
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
     constexpr int R1 = kFusedMaxR + 1;
     const int64_t bp = st.bpad;
@@ -2886,6 +2891,27 @@ __global__ __launch_bounds__(64) void k_gemm_nn(int n, double *OUT, int64_t ldo,
       }
     }
   }
+}
+
+// The upper-triangle entries that cross from one XCD chunk into the next: alpha's share of them, after the pass (a kernel boundary
+// makes every chunk's rows visible everywhere). One wave per edge and iteration: acc += val * W[r] * W[c] (val = the doubled
+// off-diagonal entry, as in the upper-triangle streams); per-block column sums into out[blockIdx.x][bpad].
+template <typename F, int LPR>
+__global__ __launch_bounds__(kBlock) void k_alpha_edges(int n, int nedges, const int32_t *__restrict__ er, const int32_t *__restrict__ ec, const F *__restrict__ ev,
+                                                        const F *__restrict__ W /* slot of W_{j+1} */, double *__restrict__ out, int bpad) {
+  using VF = typename VecT<F>::type;
+  constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW;
+  static_assert(LPR == 64, "whole-row panels");
+  __shared__ double red[kWaves * 64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int panel = blockIdx.y;
+  const F *Wp = W + (int64_t)panel * n * PW + lane * V;
+  VF acc = (VF)(F)0;
+  for (int e = blockIdx.x * kWaves + wave; e < nedges; e += gridDim.x * kWaves) {
+    const VF a = *(const VF *)(Wp + (int64_t)er[e] * PW), b = *(const VF *)(Wp + (int64_t)ec[e] * PW);
+    acc += (ev[e] * a) * b;
+  }
+  block_reduce_columns<F, LPR>(acc, red, out + (int64_t)blockIdx.x * bpad + panel * PW);
 }
 
 }  // namespace slq

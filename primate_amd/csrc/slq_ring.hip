@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -c -DRING_F=double -DRING_LPR=32 -DRING_TAG=f64_l32 slq_ring.hip -o ring_f64_l32.o
 #include "slq_ring_api.h"
 #include "slq_ring.hpp"
+#include "slq_ring_fa.hpp"
 
 #ifndef RING_F
 #error "compile with -DRING_F=<double|float> -DRING_LPR=<64|32|16> -DRING_TAG=<f64_l64|...>"
@@ -66,8 +67,58 @@ int CAT(slq_ring_launch_, RING_TAG)(const RingArgs &a) {
   }
 }
 
+// the update pass with the next step's alpha dot fused in (slq_ring_fa.hpp): whole-row panels only
+namespace {
+template <int RC> int launch_fa(const RingArgs &a) {
+  if constexpr (L == 64) {
+    k_ring_fa<F, RC><<<a.grid, dim3(16 * 64), RingGeo<64, 16, 0>::kLdsBytes, a.st>>>(a.n, a.desc, a.rec, a.desc_a, a.rec_a, a.xr, (F *)a.ring, a.slot_stride, a.S, a.j, a.coefA,
+                                                                                     a.coefB, a.gamma, a.part, a.bpad, a.cnt, a.cnt_rounds, a.gen, a.xcc_tab, a.fail, a.xt);
+    return 0;
+  } else {
+    return -1;
+  }
+}
+template <int RC> hipError_t prepare_fa() {
+  if constexpr (L == 64) return hipFuncSetAttribute((const void *)k_ring_fa<F, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  else return hipSuccess;
+}
+template <int RC> int vgprs_fa() {
+  if constexpr (L == 64) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, (const void *)k_ring_fa<F, RC>) != hipSuccess) return -1;
+    return at.numRegs + ((int)(at.localSizeBytes > 0) << 16);
+  } else {
+    return -1;
+  }
+}
+}  // namespace
+
+int CAT(slq_ring_fa_launch_, RING_TAG)(const RingArgs &a) {
+  if (a.pass == PASS_UPDATE && a.rc == 0) return launch_fa<0>(a);
+  if (a.pass != PASS_UPDATEG) return -1;
+  switch (a.rc) {
+    case 1: return launch_fa<1>(a);
+    case 2: return launch_fa<2>(a);
+    case 3: return launch_fa<3>(a);
+    default: return -1;
+  }
+}
+int CAT(slq_ring_fa_vgprs_, RING_TAG)(int rc) {
+  switch (rc) {
+    case 0: return vgprs_fa<0>();
+    case 1: return vgprs_fa<1>();
+    case 2: return vgprs_fa<2>();
+    case 3: return vgprs_fa<3>();
+    default: return -1;
+  }
+}
+
 hipError_t CAT(slq_ring_prepare_, RING_TAG)() {
   hipError_t e = prepare<PASS_ALPHA, 0>();
+  if (e == hipSuccess) e = prepare_fa<0>();
+  if (e == hipSuccess) e = prepare_fa<1>();
+  if (e == hipSuccess) e = prepare_fa<2>();
+  if (e == hipSuccess) e = prepare_fa<3>();
   if (e == hipSuccess) e = prepare<PASS_ALPHA, 0, 1>();
   if (e == hipSuccess) e = prepare<PASS_SPMM, 0>();
   if (e == hipSuccess) e = prepare<PASS_UPDATE, 0>();

@@ -22,13 +22,23 @@ struct RingArgs {
   int bpad, xt;
   int *fail;
   unsigned long long *dbg;  // -DSLQ_DEBUG_TIMES builds: the stamp buffer (else null)
+  // the update pass with the next step's alpha dot fused in (slq_ring_fa.hpp; slq_ring_fa_launch_*): the operator's interior
+  // upper-triangle stream, the chunk counters [NP][8][cnt_rounds] (zeroed at the start of a run), this pass's number within the run
+  // (1, 2, ...: the counters' target is gen x workgroups per XCD), the XCC table [8] (zeroed with the counters)
+  const int32_t *desc_a = nullptr;
+  const char *rec_a = nullptr;
+  int *cnt = nullptr;
+  int cnt_rounds = 0, gen = 0;
+  int *xcc_tab = nullptr;
 };
 
 // launch: 0, or -1 when the object has no kernel for (pass, rc). prepare: raises the dynamic-LDS limit of all its kernels.
 #define SLQ_RING_DECLARE(TAG)                   \
   int slq_ring_launch_##TAG(const RingArgs &a); \
   hipError_t slq_ring_prepare_##TAG();          \
-  int slq_ring_vgprs_##TAG(int pass, int rc);
+  int slq_ring_vgprs_##TAG(int pass, int rc);   \
+  int slq_ring_fa_launch_##TAG(const RingArgs &a); /* pass: PASS_UPDATEG (rc 1..3) or PASS_UPDATE (rc 0); -1: no such kernel */ \
+  int slq_ring_fa_vgprs_##TAG(int rc);
 SLQ_RING_DECLARE(f64_l64)
 SLQ_RING_DECLARE(f32_l64)
 SLQ_RING_DECLARE(f64_l32)

@@ -933,6 +933,35 @@ def test_alpha_pass_stream_forms(oracle, eng, monkeypatch, env):
 		op.close()
 
 
+def test_opt_in_fused_update_and_alpha_pass(oracle, eng, monkeypatch):
+	"""SLQ_FUSED_ALPHA=1 (opt-in, slq_ring_fa.hpp): the update pass of step j also takes step j + 1's alpha dot a fixed lag of tile
+	rounds behind its own write front (same-XCD hand-off through L2 counters), entries that cross XCD chunks by a small edge kernel.
+	Same alpha as the alpha-only pass up to the order of the sum (q_c . (A q_c - beta q_p), lanczos.h:127-129): per-probe values
+	against the oracle on a 2-D and a 3-D grid, orth 1..3, and against the default sequence to rounding. Measured slower than the
+	two passes it replaces, hence not the default."""
+	monkeypatch.setenv("SLQ_TILES", "2")
+	rng = np.random.default_rng(41)
+	for A in (laplacian_2d(200), laplacian_3d(40)):
+		n = A.shape[0]
+		P = 130
+		X = np.asfortranarray(np.floor(rng.random((n, P)) * 2) * 2 - 1)
+		cols = [0, P // 2, P - 1]
+		op = eng.DeviceOperator(A)
+		for orth in (1, 2, 3):
+			base = eng.quad_batch(op, X, 14, orth, fun="log")
+			monkeypatch.setenv("SLQ_FUSED_ALPHA", "1")
+			plan = eng.LanczosPlan(op, P, 14, orth)
+			assert plan.describe()["fused_alpha"] == 1 and plan.describe()["sequence"] == "fused_gram"
+			plan.set_probes(X)
+			plan.run()
+			got = plan.quadrature("log")
+			plan.close()
+			monkeypatch.delenv("SLQ_FUSED_ALPHA")
+			np.testing.assert_allclose(got, base, rtol=1e-12)
+			np.testing.assert_allclose(got[cols], oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 14, orth, fun="log", fresh_q=True), rtol=1e-10)
+		op.close()
+
+
 FUNS_LONG = [("log", {}), ("exp", {"t": -0.1}), ("inv", {}), ("numrank", {}), ("step", {"c": 1.0})]
 
 
