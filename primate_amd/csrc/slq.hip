@@ -236,6 +236,7 @@ struct slq_plan {
   bool ring_gen;              // every ring-fed pass of the plan runs k_ring_pass (always for ringR > 1; SLQ_RING_GEN for ringR = 1)
   bool ring_deep;             // steps with 4..8 ring columns run k_ring_pass with 8 waves (SLQ_RING_DEEP; else the generic passes)
   bool gram;                  // steps with 1..8 ring columns take their projections from Gram rows of the update passes (SLQ_GRAM)
+  bool gram_csr;              // ... also where the plan's fused passes are the generic ones (k_csr_pass<PASS_UPDATEG>: narrow panels, small operators; SLQ_GRAM_CSR, r04)
   const int32_t *rs_desc, *rs_desc_u;  // the stream the plan's ring-fed passes read (full rows / upper triangle or null)
   const char *rs_rec, *rs_rec_u;
   bool rs_u_padded;            // ... whose rows are padded to whole chunks of four entries (the alpha-only pass's branch-free consumer)
@@ -2107,13 +2108,19 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
       // faster form there, configs[1] 0.129 -> 0.113). SLQ_RING_STAGED=1 takes the loaders through registers (GEO 1) again.
       p->ring_staged = env_int("SLQ_RING_STAGED", 0) != 0;
       // the Gram sequence needs every step of the window on k_ring_pass (PASS_UPDATEG), i.e. the deep form too
-      p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && env_int("SLQ_GRAM", 1) != 0;
+      // (and an EXACTLY symmetric operator: the sequence rewrites W_t . (A W_j) as (A W_t) . W_j - §4.6 - while the reference's recurrence never
+      // looks at symmetry, lanczos.h:127-136; rowptr_u is the record of that check. r04: r03 took the sequence on any tiled operator)
+      p->gram = p->ring_gen && p->ring_deep && p->sw.merged && !p->sw.mgs && op->rowptr_u != nullptr && env_int("SLQ_GRAM", 1) != 0;
       // fused alpha: whole-row panels on the Gram sequence with at most kRingMaxR ring columns per step, descending update sweeps,
       // the alpha-only pass on the padded upper-triangle stream (step 0 still runs it), and the interior stream buildable
       p->fa_on = p->sw.fused_alpha && !g_fa_broken.load() && p->gram && p->ringR == 1 && p->sw.ring_rev && p->rs_desc_u != nullptr && p->rs_u_padded &&
                  p->sw.ring_alpha == 2 && orth >= 1 && orth <= kRingMaxR && ensure_fa_stream(op);
     }
   }
+  // the Gram sequence on the generic passes (no tiles, or a plan whose panels the tiles do not serve): the dots pass - a third to a half of every
+  // step's bytes - is gone there as well. Not for operators whose gathers are the cost (random graphs keep the stored-u sequence: it gathers once,
+  // the Gram sequence twice) - enqueue_run decides that per step exactly as before.
+  p->gram_csr = op->kind == OP_CSR && p->ringR == 0 && op->rowptr_u != nullptr && p->sw.merged && !p->sw.mgs && p->sw.nt && env_int("SLQ_GRAM", 1) != 0 && env_int("SLQ_GRAM_CSR", 1) != 0;
   {
     // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
     // per CU and panel in the grid, panel after panel
@@ -2278,8 +2285,24 @@ template <typename F, int L> static hipError_t raise_lds_limits() {
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 7, 0>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 7, 0>,
       (const void *)k_csr_pass<F, L, PASS_UPDATE, 0, 8, 0>,
-      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8, 0>};
+      (const void *)k_csr_pass<F, L, PASS_UPDATE, 1, 8, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 1, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 2, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 3, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 4, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 5, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 6, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 7, 0>,
+      (const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 8, 0>};
   if constexpr (L == 64) {
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 1, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 2, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 3, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 4, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 5, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 6, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 7, 1>);
+    fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_UPDATEG, 1, 8, 1>);
     fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 1, 1>);
     fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 1, 1, 1>);
     fused_fns.push_back((const void *)k_csr_pass<F, L, PASS_DOTS, 0, 2, 1>);
@@ -2417,7 +2440,7 @@ static int plan_sequence(const slq_plan *p) {
   const slq_operator *op = p->op;
   if (p->ring32_on) return 3;
   if (op->kind != OP_CSR || p->sw.fused == 0 || p->sw.mgs || p->nstale > 0) return 0;
-  if (p->sw.fused == 2 || op->far_per_row <= 4.0) return (p->gram && p->orth >= 1 && plan_tiled(p)) ? 4 : 1;
+  if (p->sw.fused == 2 || op->far_per_row <= 4.0) return (((p->gram && plan_tiled(p)) || p->gram_csr) && p->orth >= 1) ? 4 : 1;
   return (p->orth >= 1 && p->sw.stored_u && p->sw.merged && !plan_tiled(p)) ? 2 : 0;
 }
 
@@ -2751,6 +2774,21 @@ static int quadrature_lanes(int deg) {
   return std::max(1, std::min(64, lanes));
 }
 
+// the generic update pass of the Gram sequence (k_csr_pass<PASS_UPDATEG>, nontemporal streams), r = 1 .. kFusedMaxR ring columns
+template <typename F, int L, int RC> static inline void launch_csr_updateg_rc(slq_plan *p, bool pipe_on, dim3 grid, size_t lds, hipStream_t st, int j);
+template <typename F, int L> static inline void launch_csr_updateg(slq_plan *p, int r, bool pipe_on, dim3 grid, size_t lds, hipStream_t st, int j) {
+  switch (r) {
+    case 1: launch_csr_updateg_rc<F, L, 1>(p, pipe_on, grid, lds, st, j); break;
+    case 2: launch_csr_updateg_rc<F, L, 2>(p, pipe_on, grid, lds, st, j); break;
+    case 3: launch_csr_updateg_rc<F, L, 3>(p, pipe_on, grid, lds, st, j); break;
+    case 4: launch_csr_updateg_rc<F, L, 4>(p, pipe_on, grid, lds, st, j); break;
+    case 5: launch_csr_updateg_rc<F, L, 5>(p, pipe_on, grid, lds, st, j); break;
+    case 6: launch_csr_updateg_rc<F, L, 6>(p, pipe_on, grid, lds, st, j); break;
+    case 7: launch_csr_updateg_rc<F, L, 7>(p, pipe_on, grid, lds, st, j); break;
+    default: launch_csr_updateg_rc<F, L, 8>(p, pipe_on, grid, lds, st, j); break;
+  }
+}
+
 // one dots sweep of the store-and-revisit sequence, with or without the fp32 archive
 // (deferred: the block-CGS sweeps leave `w -= cB W_c` to the update sweep - every dots chunk applies it in registers and stores
 // nothing; the fp32-archive kernels keep the stored form)
@@ -2789,6 +2827,12 @@ static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStrea
     }
   }
   k_csr_pass<F, L, PASS, LP, RC, 0><<<grid, dim3(kBlock), lds, st>>>(args...);
+}
+
+template <typename F, int L, int RC> static inline void launch_csr_updateg_rc(slq_plan *p, bool pipe_on, dim3 grid, size_t lds, hipStream_t st, int j) {
+  const slq_operator *op = p->op;
+  launch_csr_pass<F, L, PASS_UPDATEG, 1, RC>(pipe_on, grid, lds, st, p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
+                                             p->st.coefB, p->st.gamma, p->part, p->bpad, 0);
 }
 
 // the same pass on workgroup tiles (wide panels only; slq_kernels.hpp: k_csr_tile_pass)
@@ -2921,6 +2965,7 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
   // alpha and nu[1..] start from zero (the reference's fresh np.zeros buffers, lanczos.py:101-102)
   HIP_TRY(hipMemsetAsync(p->st.alpha, 0, (size_t)(deg + 1) * bp * 8, st));
   HIP_TRY(hipMemsetAsync(p->st.nu + bp, 0, (size_t)deg * bp * 8, st));
+  HIP_TRY(hipMemsetAsync(p->st.gram, 0, (size_t)2 * (kFusedMaxR + 1) * bp * 8, st));  // (the Gram rows of a previous run are never read - index guards - but need not be trusted to be)
   if (p->fa_on) HIP_TRY(hipMemsetAsync(p->fa_cnt, 0, ((size_t)p->NP * 8 * p->fa_rounds + 8) * sizeof(int), st));
   int fa_gen = 0;         // fused update + alpha passes launched so far in this run (their counters' generation)
   int fa_alpha_slab = -1; // >= 0: step j's alpha dot was taken by step j - 1's update pass and lies in this slab of `part` (raw: not yet / nu^2)
@@ -3048,6 +3093,19 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
         continue;
       }
       fa_alpha_slab = -1;
+      // the same sequence on the generic passes (k_csr_pass<PASS_UPDATEG>; r04): alpha-only pass over the upper triangle, projections from Gram rows
+      if (p->gram_csr && !tiled && gathers_cached && !stored_u && r >= 1 && p->nstale == 0) {
+        const int xa = j > 0 ? 1 : 0;
+        PROFILED(p, SLQ_K_SPMM, { if (nt) CSR_PASS(PASS_ALPHA, 1, 1, 0, 0, ldsA, xa); else CSR_PASS(PASS_ALPHA, 0, 0, 0, 0, ldsA, xa); });
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_gram, dim3((bp + 63) / 64, r), dim3(kFinThreads), 0, st, p->st, p->part, alpha_tiled ? p->nblkT : p->nblkF, j, r, orth_tol,
+                                    (const double *)nullptr, 0, 0));
+        PROFILED(p, SLQ_K_REORTH_UPD, DISPATCH(p->dtype, p->LPR, (launch_csr_updateg<F, L>(p, r, pipe_on, gU, lds0 + fused_pad, st, j))));
+        PROFILED(p, SLQ_K_FINALIZE,
+                 hipLaunchKernelGGL(k_fin_beta_gram, dim3((bp + 63) / 64, r + 1), dim3(kFinThreads), 0, st, p->st, p->part, p->nblkU, j, r, residual_tol));
+        prev_xt = false;
+        continue;
+      }
       if (merged) {
         PROFILED(p, SLQ_K_REORTH_DOT, { if (nt) CSR_PASS(PASS_ADOTS, 1, 1, 0, r, lds0 + fused_pad, su); else CSR_PASS(PASS_ADOTS, 0, 0, 0, r, lds0 + fused_pad, su); });
         PROFILED(p, SLQ_K_FINALIZE,

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
     cp[v] = (F)coefA[bpad + colbase + v];
     if (PASS != PASS_ALPHA) cb[v] = (F)coefB[colbase + v];
   }
-  if (PASS == PASS_UPDATE) {
+  if (PASS == PASS_UPDATE || PASS == PASS_UPDATEG) {
 #pragma unroll
     for (int i = 0; i < RC; ++i)
 #pragma unroll
@@ -398,6 +398,38 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
         }
         p = p1;
       }
+      if constexpr (RPW > 1) {
+        // several rows per wave (narrow panels): a row's last two or three entries go as ONE batch - indices clamped to the row's last
+        // entry, coefficients of the surplus zero - instead of one dependent colind -> gather round trip each (r04: the upper triangle
+        // of a 5-point grid is three entries per row, i.e. three round trips in the loops below; same products in the same order, plus zeros)
+        for (; p + 4 <= p1; p += 4) {
+          const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
+          const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
+          const VF x0 = *(const VF *)(wc + (int64_t)c0 * PW);
+          const VF x1 = *(const VF *)(wc + (int64_t)c1 * PW);
+          const VF x2 = *(const VF *)(wc + (int64_t)c2 * PW);
+          const VF x3 = *(const VF *)(wc + (int64_t)c3 * PW);
+          acc += a0 * x0;
+          acc += a1 * x1;
+          acc += a2 * x2;
+          acc += a3 * x3;
+        }
+        if (p + 2 <= p1) {  // two or three entries left: one masked batch (a single one goes through the loop below: one gather, not four)
+          const int last = p1 - 1;
+          const int q1 = min(p + 1, last), q2 = min(p + 2, last), q3 = min(p + 3, last);
+          const int c0 = colind[p], c1 = colind[q1], c2 = colind[q2], c3 = colind[q3];
+          const F a0 = vals[p], a1 = p + 1 <= last ? vals[q1] : (F)0, a2 = p + 2 <= last ? vals[q2] : (F)0, a3 = p + 3 <= last ? vals[q3] : (F)0;
+          const VF x0 = *(const VF *)(wc + (int64_t)c0 * PW);
+          const VF x1 = *(const VF *)(wc + (int64_t)c1 * PW);
+          const VF x2 = *(const VF *)(wc + (int64_t)c2 * PW);
+          const VF x3 = *(const VF *)(wc + (int64_t)c3 * PW);
+          acc += a0 * x0;
+          acc += a1 * x1;
+          acc += a2 * x2;
+          acc += a3 * x3;
+          p = p1;
+        }
+      }
       for (; p + 4 <= p1; p += 4) {
         const int c0 = colind[p], c1 = colind[p + 1], c2 = colind[p + 2], c3 = colind[p + 3];
         const F a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
@@ -450,7 +482,16 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
           for (int i = 2; i < RC; ++i) w -= gm[i] * u[i - 2];
           stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += w * w;
-          accx += w * xc;
+          if constexpr (PASS == PASS_UPDATEG) {
+            // Gram sequence outside the ring-fed tiles (r04): the new vector against every ring column the pass
+            // holds in registers anyway - the NEXT step's projections are assembled from these rows (k_fin_gram), no dots pass
+            if constexpr (RC > 0) dacc[0] += w * xc;
+            if constexpr (RC > 1) dacc[1] += w * xp;
+#pragma unroll
+            for (int i = 2; i < RC; ++i) dacc[i] += w * u[i - 2];
+          } else {
+            accx += w * xc;
+          }
         }
       }
     }
@@ -476,6 +517,11 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
       block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)i * nblk + blockIdx.x) * bpad + panel * PW);
       block_reduce_columns<F, LPR>(gacc[i], red, part + ((int64_t)(RC - 1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
     }
+  } else if (PASS == PASS_UPDATEG) {
+    // slab 0: ||w||^2; slab 1 + q: w . W_{j-q} (the layout k_ring_pass<PASS_UPDATEG> writes: k_fin_beta_gram reads either)
+    block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
+#pragma unroll
+    for (int i = 0; i < RC; ++i) block_reduce_columns<F, LPR>(dacc[i], red, part + ((int64_t)(1 + i) * nblk + blockIdx.x) * bpad + panel * PW);
   } else {
     block_reduce_columns<F, LPR>(acc1, red, part + (int64_t)blockIdx.x * bpad + panel * PW);
     if (PASS == PASS_UPDATE && xt)

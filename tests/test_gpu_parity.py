@@ -192,9 +192,44 @@ def test_probe_count_edges(oracle, eng, nprobes):
 	rng = np.random.default_rng(nprobes)
 	X = np.asfortranarray(np.floor(rng.random((A.shape[0], nprobes)) * 2) * 2 - 1)
 	op = eng.DeviceOperator(A)
+	## (no tiles at this size: the generic passes, on the Gram sequence since r04 - k_csr_pass<PASS_UPDATEG>)
+	plan = eng.LanczosPlan(op, nprobes, 12, 3)
+	assert plan.describe()["sequence"] == "fused_gram" and plan.describe()["tiles"] == 0, plan.describe()
+	plan.close()
 	got = eng.quad_batch(op, X, 12, 3, fun="log")
 	ref = oracle.quad_batch(A, X, 12, 3, fun="log", fresh_q=True)
 	np.testing.assert_allclose(got, ref, rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-10), (np.float32, 3e-4)])
+def test_gram_sequence_on_the_generic_passes(oracle, eng, monkeypatch, dtype, tol):
+	"""The Gram sequence where the plan's fused passes are the generic ones (r04: k_csr_pass<PASS_UPDATEG>; operators below the tiles' size,
+	panels of 8 lanes per row, the single-vector lanczos() - src/primate/lanczos.py:109; hutch draws one probe per iteration,
+	src/primate/trace.py:104-116): every window 1..8 and a window that hands over to the sweeps (orth 12), panels of 1 / 7 / 16 / 40 / 130
+	probes (all four panel widths, several rows per wave and one), a 2-D and a 3-D grid and an irregular graph with empty rows whose rows
+	end in 1, 2 and 3 leftover entries (the masked last batch of the narrow panels' row loop), against the oracle; SLQ_GRAM_CSR=0 (the
+	merged alpha+dots sequence) on the same inputs. lanczos.h:43-66,127-136."""
+	rng = np.random.default_rng(8)
+	ops = [laplacian_2d(60), laplacian_3d(12), random_spd_graph(3000, 5.0, seed=17)]
+	for A in ops:
+		A = A.astype(dtype)
+		n = A.shape[0]
+		op = eng.DeviceOperator(A)
+		for P in (1, 7, 16, 40, 130):
+			X = np.asfortranarray(rng.standard_normal((n, P))).astype(dtype)
+			cols = sorted({0, P // 2, P - 1})
+			for orth in (1, 2, 3, 5, 8, 12):
+				ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 16, orth, fun="exp", t=-0.05, fresh_q=True, prefer="csr")
+				for gram in ("1", "0"):
+					monkeypatch.setenv("SLQ_GRAM_CSR", gram)
+					plan = eng.LanczosPlan(op, P, 16, orth)
+					assert plan.describe()["sequence"] == ("fused_gram" if gram == "1" else "fused") and plan.describe()["tiles"] == 0
+					plan.set_probes(X)
+					plan.run()
+					np.testing.assert_allclose(plan.quadrature("exp", t=-0.05)[cols], ref, rtol=tol, err_msg=f"n={n} P={P} orth={orth} gram={gram}")
+					plan.close()
+				monkeypatch.delenv("SLQ_GRAM_CSR")
+		op.close()
 
 
 def test_tiny_and_degenerate_operators(oracle, eng):
@@ -691,6 +726,8 @@ def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, m
 	op = eng.DeviceOperator(B)
 	for orth in (0, 3):
 		plan = eng.LanczosPlan(op, 20, 12, orth)
+		## (the Gram sequence moves A across an inner product - W_t . (A W_j) = (A W_t) . W_j - which only an exactly symmetric operator allows)
+		assert plan.describe()["sequence"] == "fused" and plan.describe()["upper_alpha"] == 0, plan.describe()
 		plan.set_probes(X)
 		plan.run()
 		a, b, _ = plan.tridiag()
@@ -699,6 +736,36 @@ def test_alpha_pass_upper_triangle_only_for_exactly_symmetric_csr(oracle, eng, m
 			oracle.lanczos(B, X[:, c].copy(), 12, 1e-8, orth, ar, br, Qr)
 			np.testing.assert_allclose(a[c][:12], ar[:12], rtol=1e-9, atol=1e-9)
 			np.testing.assert_allclose(b[c][1:12], br[1:12], rtol=1e-9, atol=1e-9)
+
+
+def test_non_symmetric_operator_on_tiles_keeps_the_direct_projections(oracle, eng, monkeypatch):
+	"""A tiled operator that is NOT exactly symmetric (one off-diagonal entry of a 5-point grid scaled): the ring-fed passes run the merged
+	alpha+dots sequence - the Gram sequence needs A = A^T (r03 took it regardless: fixed in r04) - and alpha / beta follow the oracle's
+	recurrence, which never checks symmetry (lanczos.h:127-136), on wide and narrow panels."""
+	monkeypatch.setenv("SLQ_TILES", "2")
+	B = laplacian_2d(100).tolil()
+	B[4321, 4322] = -1.5
+	B = B.tocsr()
+	B.sort_indices()
+	n = B.shape[0]
+	rng = np.random.default_rng(5)
+	op = eng.DeviceOperator(B)
+	for P in (130, 40):
+		X = np.asfortranarray(rng.standard_normal((n, P)))
+		for orth in (3, 6):
+			plan = eng.LanczosPlan(op, P, 14, orth)
+			info = plan.describe()
+			assert info["tiles"] == 2 and info["sequence"] == "fused" and info["upper_alpha"] == 0, info
+			plan.set_probes(X)
+			plan.run()
+			a, b, _ = plan.tridiag()
+			plan.close()
+			for c in (0, P - 1):
+				ar, br, Qr = np.zeros(15), np.zeros(15), np.zeros((n, orth), order="F")
+				oracle.lanczos(B, X[:, c].copy(), 14, 1e-8, orth, ar, br, Qr)
+				np.testing.assert_allclose(a[c][:14], ar[:14], rtol=1e-10, atol=1e-10)
+				np.testing.assert_allclose(b[c][1:14], br[1:14], rtol=1e-10, atol=1e-10)
+	op.close()
 
 
 def test_non_local_operator_uses_stored_u_passes(oracle, eng, monkeypatch):
@@ -745,13 +812,16 @@ def test_pipelined_row_loop_with_empty_rows(oracle, eng, monkeypatch, dtype, rto
 	monkeypatch.setenv("SLQ_TILES", "0")
 	monkeypatch.setenv("SLQ_FUSED", "2")  # the recompute passes whatever the gather distances
 	op = eng.DeviceOperator(A)
-	plan = eng.LanczosPlan(op, P, 12, 3)
-	assert plan.describe()["pipelined"] == 1 and plan.describe()["sequence"] == "fused"
-	plan.close()
-	for orth in (0, 3, 6):
-		ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, orth, fun="exp", t=-0.01, fresh_q=True, prefer="csr")
-		got = eng.quad_batch(op, X, 12, orth, fun="exp", t=-0.01)[cols]
-		np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"orth={orth}")
+	## both sequences of the generic passes: merged alpha+dots + update (SLQ_GRAM_CSR=0) and, the default since r04, alpha + update on Gram rows
+	for gram_csr, seq in (("0", "fused"), ("1", "fused_gram")):
+		monkeypatch.setenv("SLQ_GRAM_CSR", gram_csr)
+		plan = eng.LanczosPlan(op, P, 12, 3)
+		assert plan.describe()["pipelined"] == 1 and plan.describe()["sequence"] == seq, plan.describe()
+		plan.close()
+		for orth in (0, 3, 6):
+			ref = oracle.quad_batch(A, np.asfortranarray(X[:, cols]), 12, orth, fun="exp", t=-0.01, fresh_q=True, prefer="csr")
+			got = eng.quad_batch(op, X, 12, orth, fun="exp", t=-0.01)[cols]
+			np.testing.assert_allclose(got, ref, rtol=rtol, err_msg=f"orth={orth} {seq}")
 	op.close()
 
 
