@@ -64,10 +64,12 @@ double oracle_apply_fun(int fun_id, const double *params, double x) {
 #undef F_SQRT
 #undef F_FABS
 #undef F_HYPOT
+#undef F_BLOCKED_DOT
 
 #define F float
 #define FN(x) x##_f32
 #define F_EPS FLT_EPSILON
+#define F_BLOCKED_DOT 1 /* fp32 reductions blocked the way Eigen's packet reductions are (slq_oracle_impl.h: dot) */
 #define F_SQRT sqrtf
 #define F_FABS fabsf
 #define F_HYPOT hypotf
@@ -79,3 +81,4 @@ double oracle_apply_fun(int fun_id, const double *params, double x) {
 #undef F_SQRT
 #undef F_FABS
 #undef F_HYPOT
+#undef F_BLOCKED_DOT

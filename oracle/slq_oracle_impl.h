@@ -73,10 +73,29 @@ static int FN(op_apply)(const FN(oracle_operator) * A, const F *x, F *y) {
   }
 }
 
+/* Inner product. The reference's are Eigen's `dot` / `squaredNorm` (src/primate/include/lanczos.h:59-63,129,139), which Eigen
+ * 3.4 evaluates packet-wise: a packet of 8 floats (AVX) per accumulator, four accumulators unrolled, the four added pairwise,
+ * the eight lanes of the result by a tree, the tail element by element. fp32 (F_BLOCKED_DOT): restated in that shape - 32
+ * running sums - because ONE sequential fp32 accumulator is 0.7 % off at n = 2e6 (the oracle, not the thing
+ * checked, was the noisy side at configs[3]'s size), which the reference is not. fp64 keeps the sequential sum the golden
+ * vectors were pinned with (its rounding is far below every tolerance in use). */
 static F FN(dot)(int64_t n, const F *a, const F *b) {
+#ifdef F_BLOCKED_DOT
+  F acc[32];
+  for (int k = 0; k < 32; ++k) acc[k] = (F)0;
+  int64_t i = 0;
+  for (; i + 32 <= n; i += 32)
+    for (int k = 0; k < 32; ++k) acc[k] += a[i + k] * b[i + k];
+  F lane[8];
+  for (int l = 0; l < 8; ++l) lane[l] = (acc[l] + acc[8 + l]) + (acc[16 + l] + acc[24 + l]);
+  F s = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+  for (; i < n; ++i) s += a[i] * b[i];
+  return s;
+#else
   F s = (F)0;
   for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
+#endif
 }
 
 /* Modified Gram-Schmidt of v against p cyclic columns of U (n x m, column-major), starting at

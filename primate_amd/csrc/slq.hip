@@ -247,6 +247,7 @@ struct slq_plan {
   int *fa_cnt = nullptr;      // chunk counters [NP][8][fa_rounds] + the XCC table [8], zeroed at the start of every run
   int fa_rounds = 0;
   int part_maxblk = 0;        // blocks per slab of `part`
+  bool launch_error = false;  // a launcher declined (mis-dispatch): the run is invalid (enqueue_run)
 };
 
 // SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
@@ -978,10 +979,11 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     // every column index inside [0, n): ranges of the array in parallel, the first offender (lowest position) reported
     const int pieces = host_threads();
     std::vector<int64_t> bad((size_t)pieces, -1);
-    parallel_pieces(pieces, nnz, [&](int piece, int64_t p0, int64_t p1) {
-      for (int64_t p = p0; p < p1; ++p)
-        if (colind[p] < 0 || colind[p] >= n) { bad[(size_t)piece] = p; break; }
-    });
+    if (!parallel_pieces(pieces, nnz, [&](int piece, int64_t p0, int64_t p1) {
+          for (int64_t p = p0; p < p1; ++p)
+            if (colind[p] < 0 || colind[p] >= n) { bad[(size_t)piece] = p; break; }
+        }))
+      return fail(SLQ_ENOMEM, "host worker failed while validating the column indices");
     for (int64_t b : bad)
       if (b >= 0) return fail(SLQ_EINVAL, "column index %d out of range at position %lld", colind[b], (long long)b);
   }
@@ -1019,7 +1021,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     const int pieces = 8;  // (a fixed partition: the sum does not depend on how many threads ran it)
     std::vector<double> acc((size_t)pieces, 0.0);
     std::vector<int64_t> cnt((size_t)pieces, 0);
-    parallel_pieces(pieces, n, [&](int piece, int64_t i0, int64_t i1) {
+    if (!parallel_pieces(pieces, n, [&](int piece, int64_t i0, int64_t i1) {
       double a = 0.0;
       int64_t c = 0;
       for (int64_t i = i0; i < i1; ++i) {
@@ -1034,7 +1036,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       }
       acc[(size_t)piece] = a;
       cnt[(size_t)piece] = c;
-    });
+    })) throw std::bad_alloc();
     double a = 0.0;
     int64_t c = 0;
     for (int t = 0; t < pieces; ++t) a += acc[(size_t)t], c += cnt[(size_t)t];  // (piece order: the same value whatever the timing)
@@ -1075,7 +1077,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     // distinct indices per tile row, on the caller's numbering (the exact lists are built below); tile ranges in parallel
     const int pieces = host_threads();
     std::vector<int64_t> dpart((size_t)pieces, 0);
-    parallel_pieces(pieces, (int64_t)tile_row.size() - 1, [&](int piece, int64_t t0, int64_t t1) {
+    if (!parallel_pieces(pieces, (int64_t)tile_row.size() - 1, [&](int piece, int64_t t0, int64_t t1) {
       std::vector<int32_t> u;
       int64_t d = 0;
       for (int64_t t = t0; t < t1; ++t) {
@@ -1089,7 +1091,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         d += (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
       }
       dpart[(size_t)piece] = d;
-    });
+    })) throw std::bad_alloc();  // (an undercounted sum would bias the decision whether the tiles are kept)
     int64_t dsum = 0;
     for (int64_t d : dpart) dsum += d;
     clk.lap("  lines per row");
@@ -1242,12 +1244,12 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     // gathers per row that reach further than any cache-resident halo (|i - j| > 4096 rows in the stored
     // order): what decides between the recompute passes and the store-and-revisit sweeps (enqueue_run)
     std::vector<int64_t> farp((size_t)host_threads(), 0);
-    parallel_pieces((int)farp.size(), n, [&](int piece, int64_t i0, int64_t i1) {
+    if (!parallel_pieces((int)farp.size(), n, [&](int piece, int64_t i0, int64_t i1) {
       int64_t f = 0;
       for (int64_t i = i0; i < i1; ++i)
         for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) f += std::llabs((long long)colind[q] - (long long)i) > 4096;
       farp[(size_t)piece] = f;
-    });
+    })) return bail(SLQ_ENOMEM, "host worker failed (far-gather count)", hipSuccess);
     int64_t far = 0;
     for (int64_t f : farp) far += f;
     op->far_per_row = (double)far / (double)n;
@@ -2552,10 +2554,11 @@ extern "C" int slq_plan_set_probes(slq_plan *p, const void *X, int64_t ldx) {
       if (ctx->pin_busy[buf]) HIP_TRY(hipEventSynchronize(ctx->pin_ev[buf]));  // its previous transfer has left the buffer
       char *dst = (char *)ctx->pin[buf];
       // rows of the chunk cut into pieces: every thread copies its row range of every column (contiguous runs)
-      parallel_pieces(host_threads(), p->n, [&](int, int64_t r0, int64_t r1) {
-        for (int c = 0; c < nc; ++c)
-          memcpy(dst + (size_t)c * col_bytes + (size_t)r0 * p->esz, src + (size_t)c * (size_t)ldx * p->esz + (size_t)r0 * p->esz, (size_t)(r1 - r0) * p->esz);
-      });
+      if (!parallel_pieces(host_threads(), p->n, [&](int, int64_t r0, int64_t r1) {
+            for (int c = 0; c < nc; ++c)
+              memcpy(dst + (size_t)c * col_bytes + (size_t)r0 * p->esz, src + (size_t)c * (size_t)ldx * p->esz + (size_t)r0 * p->esz, (size_t)(r1 - r0) * p->esz);
+          }))
+        return fail(SLQ_ENOMEM, "host worker failed while staging the probes");
       HIP_TRY(hipMemcpyAsync(p->stage, dst, (size_t)nc * col_bytes, hipMemcpyHostToDevice, st));
       HIP_TRY(hipEventRecord(ctx->pin_ev[buf], st));
       ctx->pin_busy[buf] = true;
@@ -2854,7 +2857,7 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
       }
     }
     if (op->tiles_ringed) {  // never reached (enqueue_run sends ring-sized tiles to the ring-fed kernels or the generic passes)
-      fprintf(stderr, "[slq] internal: barrier-phased tile pass asked for on ring-sized tiles (pass %d, %d ring columns)\n", PASS, RC);
+      p->launch_error = true;  // (no launch: enqueue_run turns this into SLQ_EINVAL instead of handing out numbers of a pass that never ran)
       return;
     }
     if constexpr (PASS != PASS_SPMM)
@@ -3212,6 +3215,10 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
              hipLaunchKernelGGL(k_fin_beta, gF, dim3(kFinThreads), 0, st, p->st, p->part, nblk_last, j, residual_tol, prev_xt ? 1 : 0));
   }
   HIP_TRY(hipGetLastError());
+  if (p->launch_error) {
+    p->launch_error = false;
+    return fail(SLQ_EINVAL, "internal: a pass of the launch sequence had no kernel for this plan's tiles");
+  }
   return SLQ_OK;
 }
 
@@ -3594,8 +3601,8 @@ extern "C" int slq_dmat_copy_rows(slq_dmat *dst, int d0, int64_t dr0, slq_dmat *
   SLQ_TRY(dmat_range(dst, d0, nc, "slq_dmat_copy_rows(dst)"));
   SLQ_TRY(dmat_range(src, s0, nc, "slq_dmat_copy_rows(src)"));
   if (dst->ctx != src->ctx) return fail(SLQ_EINVAL, "mismatched operands");
+  if (nrows == 0) return SLQ_OK;  // (an empty shard - more ranks than rows - copies nothing, wherever it nominally starts)
   if (nrows < 0 || dr0 < 0 || sr0 < 0 || dr0 + nrows > dst->n || sr0 + nrows > src->n) return fail(SLQ_EINVAL, "row range outside the matrix");
-  if (nrows == 0) return SLQ_OK;
   HIP_TRY(hipSetDevice(dst->ctx->device));
   HIP_TRY(hipMemcpy2DAsync(dst->d + (size_t)d0 * dst->n + dr0, (size_t)dst->n * 8, src->d + (size_t)s0 * src->n + sr0, (size_t)src->n * 8,
                            (size_t)nrows * 8, (size_t)nc, hipMemcpyDeviceToDevice, dst->ctx->stream));

@@ -273,6 +273,7 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 	P = min(int(count), n)
 	nr = -(-n // world)  # rows per rank; the last ranks' shards are shorter (zero rows behind them: nothing to any Gram matrix)
 	rows_of = lambda q: max(0, min(nr, n - q * nr))  # noqa: E731
+	row0 = lambda q: min(q * nr, n)  # noqa: E731  (more ranks than rows: the shards past the end are empty and start AT the end, not beyond it)
 	cmax = -(-int(batch) // world)  # columns per rank and block, padded to equal shards for the all-to-all
 	Wd, Qd, Zd = (engine.DeviceMatrix(nr, P, ctx=ctx) for _ in range(3))
 	Yd, Td = engine.DeviceMatrix(nr, batch, ctx=ctx), engine.DeviceMatrix(nr, batch, ctx=ctx)
@@ -286,10 +287,22 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 		base, rem = divmod(ns, world)
 		return q * base + min(q, rem), base + (1 if q < rem else 0)
 
+	## the two plan shapes of a block - all ns probes (drawn by every rank) and this rank's nloc columns of them - live side by side for the
+	## whole call: M._plan keeps ONE plan per shape class, so asking it for both in turn would destroy and re-create two kept-basis plans
+	## (a ring of deg + 1 panels each) in every block
+	own_plans = {}
+
+	def plan_for(k: int):
+		if k not in own_plans:
+			if len(own_plans) >= 3:  # (full blocks: ns and nloc; the last, shorter block: two more - drop the oldest)
+				own_plans.pop(next(iter(own_plans))).close()
+			own_plans[k] = engine.LanczosPlan(M._op, k, M._deg, M._orth, keep_basis=True)
+		return own_plans[k]
+
 	def apply_fun(src, c0: int, nloc: int):
 		"""Yfull[:, :nloc] = f(A) src[:, c0:c0+nloc] (whole columns, this rank's share of the block)"""
 		if nloc > 0:
-			plan = M._plan(nloc, True)
+			plan = plan_for(nloc)
 			plan.set_probes_device(src.col_ptr(c0))
 			plan.run(M._rtol)
 			plan.fun_action_into(Yfull, 0, name, **kw)
@@ -297,7 +310,7 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 	def rows_from_columns(dst, o0: int, ns: int):
 		"""dst[:, o0:o0+ns] (local rows) = the block whose column shards sit in every rank's Yfull"""
 		for q in range(world):
-			SBf.copy_rows_from(q * cmax, 0, Yfull, 0, q * nr, rows_of(q), cmax)
+			SBf.copy_rows_from(q * cmax, 0, Yfull, 0, row0(q), rows_of(q), cmax)
 		alltoall_blocks(SBf, RB, group)
 		for q in range(world):
 			lo, nq = shard(ns, q)
@@ -312,7 +325,7 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 				SBb.copy_from(q * cmax, src, c0 + lo, nq)
 		alltoall_blocks(SBb, RB, group)
 		for q in range(world):
-			Xfull.copy_rows_from(0, q * nr, RB, q * cmax, 0, rows_of(q), cmax)
+			Xfull.copy_rows_from(0, row0(q), RB, q * cmax, 0, rows_of(q), cmax)
 
 	R, R_inv = np.zeros((0, 0)), np.zeros((0, 0))
 	result = EstimatorResult()
@@ -321,10 +334,10 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 		while m < P:
 			ns = min(int(batch), P - m)
 			lo, nloc = shard(ns, rank)
-			plan = M._plan(ns, True)
+			plan = plan_for(ns)
 			plan.generate_probes(pdf, seed=seed, probe_offset=m)
 			plan.get_probes_into(Wfull, 0)
-			Wd.copy_rows_from(m, 0, Wfull, 0, rank * nr, rows_of(rank), ns)
+			Wd.copy_rows_from(m, 0, Wfull, 0, row0(rank), rows_of(rank), ns)
 			apply_fun(Wfull, lo, nloc)
 			rows_from_columns(Yd, 0, ns)
 			Cm = np.zeros((m, ns))
@@ -362,6 +375,8 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 			m += ns
 			## the three m x m summaries in one all-reduce
 			S3 = allsum(np.stack([Qd.tn(0, m, Wd, 0, m), Qd.tn(0, m, Zd, 0, m), Zd.tn(0, m, Wd, 0, m)]))
+			## (pdf = None: no sphere rescaling - the reference rebinds `pdf` to its sampler before the test `pdf == "sphere"`, src/primate/trace.py:295,
+			## 305 against :207, so that branch never runs there either; primate_amd/trace.py says so at its own call)
 			t_samples = _leave_one_out_estimates(n, S3[0], S3[1], S3[2], R, R_inv, None)
 			estimator = MeanEstimator()
 			estimator.update(t_samples.ravel())
@@ -369,6 +384,8 @@ def _xtrace_row_sharded(M, count: int, batch: int, pdf: str, seed: int, group, f
 	finally:
 		for d in mats:
 			d.close()
+		for pl in own_plans.values():
+			pl.close()
 	result.criterion = CountCriterion(count=P)
 	return (result.estimate, result) if full else result.estimate
 

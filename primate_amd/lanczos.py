@@ -14,15 +14,55 @@ from ._capi import check, ptr
 from .integrate import quadrature
 
 
+## Operators already on the device, by CONTENT of the sparse matrix they were built from: creating one costs 0.1-0.2 s of host-side analysis
+## (row order, tile clusters, streams) and an upload, a Lanczos run over it 0.06 s - and the reference's MatrixFunction(A) costs nothing to construct
+## (src/primate/operators.py:55-100), so drivers build one per call. Key: shape, dtype, GPU and a 64-bit hash of indptr / indices / data (xxh3: ~10 GB/s,
+## 6 ms for configs[1]); values are weak references, so an operator lives exactly as long as something uses it. A matrix modified in place hashes
+## differently and gets a new operator.
+_OPERATORS: "weakref.WeakValueDictionary" = None
+
+
+def _sparse_key(A, dtype):
+	try:
+		import xxhash
+	except Exception:  # noqa: BLE001
+		return None
+	import scipy.sparse as sp
+
+	if not (sp.issparse(A) and A.format == "csr"):
+		return None
+	h = xxhash.xxh3_64()
+	for arr in (A.indptr, A.indices, A.data):
+		h.update(memoryview(np.ascontiguousarray(arr)).cast("B"))
+	ctx = engine.default_context()
+	import os
+
+	switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SLQ_")))  # (libslq reads its switches when an operator is created)
+	return (A.shape, str(A.dtype), str(np.dtype(dtype if dtype is not None else A.dtype)), ctx.device, int(A.nnz), h.intdigest(), switches)
+
+
 def _as_device_operator(A, dtype=None) -> engine.DeviceOperator:
+	global _OPERATORS
 	if isinstance(A, engine.DeviceOperator):
 		return A
+	key = _sparse_key(A, dtype)
+	if key is not None:
+		import weakref
+
+		if _OPERATORS is None:
+			_OPERATORS = weakref.WeakValueDictionary()
+		hit = _OPERATORS.get(key)
+		if hit is not None and getattr(hit, "_h", None):
+			return hit
+		op = engine.DeviceOperator(A, dtype=dtype)
+		_OPERATORS[key] = op
+		return op
 	cached = getattr(A, "_slq_device_operator", None)
-	if cached is not None and (dtype is None or cached.dtype == np.dtype(dtype)):
+	if cached is not None and getattr(cached, "_h", None) and (dtype is None or cached.dtype == np.dtype(dtype)):
 		return cached
 	op = engine.DeviceOperator(A, dtype=dtype)
 	try:
-		A._slq_device_operator = op  # ndarray / sparse matrices refuse attributes: then no cache
+		A._slq_device_operator = op  # ndarrays refuse attributes: then no cache
 	except Exception:  # noqa: BLE001
 		pass
 	return op

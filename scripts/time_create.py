@@ -38,3 +38,9 @@ for name, A in [("lap2d_1000", laplacian_2d(1000)), ("lap3d_100", laplacian_3d(1
 	t = time.perf_counter(); plan = eng.LanczosPlan(op, 256, 30, 3); ctx.synchronize(); dp = time.perf_counter() - t
 	print(f"{name}: operator create {dt:.3f} s (host-side checks of the scipy matrix alone: {prep*1e3:.1f} ms), plan create {dp:.3f} s, tiles {plan.describe()['tiles']}", flush=True)
 	plan.close(); op.close()
+	## what the drivers pay: MatrixFunction over the same matrix twice (r04: operators are cached by content of the sparse matrix)
+	from primate_amd.operators import MatrixFunction
+	t = time.perf_counter(); M1 = MatrixFunction(A, fun="log", deg=30); ctx.synchronize(); d1 = time.perf_counter() - t
+	t = time.perf_counter(); M2 = MatrixFunction(sp.csr_matrix(A.copy()), fun="log", deg=30); ctx.synchronize(); d2 = time.perf_counter() - t
+	print(f"    MatrixFunction(A): first {d1:.3f} s, again over an equal matrix {d2:.3f} s (same operator: {M1._op is M2._op})", flush=True)
+	del M1, M2

@@ -72,6 +72,15 @@ def test_config4_heat_kernel_diag_fp32_full_size(eng, oracle):
 	assert plan2.describe()["tiles"] == 2
 	q = plan2.quadrature("exp", t=-t)
 	np.testing.assert_allclose(q[cols], ref_q, rtol=3e-4)  # the quadrature path against the oracle, per probe
+	## ... and fp32 against fp32 at full size: since r04 the fp32 oracle's reductions are blocked the way Eigen's packet reductions are (32 running
+	## sums, oracle/slq_oracle_impl.h: dot) instead of one sequential accumulator, which was 0.7 % off at this n - the checker is no longer the noisy side
+	plan3 = eng.LanczosPlan(op, P, k, 3)
+	plan3.generate_probes("rademacher", seed=1234)
+	V32 = np.asfortranarray(plan3.get_probes()[:, cols])
+	plan3.close()
+	ref_q32 = oracle.quad_batch(A, V32, k, 3, fun="exp", t=-t, fresh_q=True)
+	np.testing.assert_allclose(ref_q32, ref_q, rtol=3e-4)  # the fp32 oracle against the fp64 one
+	np.testing.assert_allclose(q[cols], ref_q32, rtol=3e-4)
 	assert abs(numer.sum() / P - q.mean()) < 2e-4 * abs(q.mean())  # v^T f(A) v by action vs by quadrature (fp32)
 	assert abs(q.mean() - exact.sum()) < 6 * q.std(ddof=1) / np.sqrt(P)
 
