@@ -69,7 +69,7 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 FUSED_MAX_R = 8  # slq_kernels.hpp:kFusedMaxR
 
 
-def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True):
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True, norm_sweep=True):
 	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each
 	vector panel a kernel touches is read or written once, the CSR arrays once per panel of `pw`
 	probes. Launch sequences per Lanczos step (slq.hip:enqueue_run; `LanczosPlan.describe()["sequence"]`):
@@ -87,8 +87,9 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 	csr = npan * ((s + 4) * nnz + 4 * (n + 1))
 	out = {"spmm_3term": 0.0, "axpy_norm": 0.0, "reorth_dot": 0.0, "reorth_update": 0.0}
 	launches = dict.fromkeys(out, 0)
-	out["axpy_norm"] += vec  # ||v||^2 of the probes
-	launches["axpy_norm"] += 1
+	if norm_sweep:  # ||v||^2 of the probes (not for Rademacher probes drawn on the device: n, known - r04)
+		out["axpy_norm"] += vec
+		launches["axpy_norm"] += 1
 	for j in range(deg):
 		r = 0 if orth == 0 else min(j + 1, orth)
 		rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
@@ -167,7 +168,7 @@ def kernel_sources_sha256():
 	import hashlib
 
 	h = hashlib.sha256()
-	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq.hip"):
+	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq_ring_fa.hpp", "primate_amd/csrc/slq.hip"):
 		h.update((ROOT / f).read_bytes())
 	return h.hexdigest()
 
@@ -266,7 +267,8 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
 	info = plan.describe()  # panel geometry and launch sequence the library chose
 	pw, fused = info["panel_width"], not info["sequence"].startswith("sweeps")
-	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]))
+	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]),
+	                      norm_sweep=os.environ.get("SLQ_KNOWN_NORM", "1") == "0")  # (the bench draws Rademacher probes on the device)
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)
 	launches = prof[dom]["launches"]
@@ -291,7 +293,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 			**({"alg_GBps": round(kb[k] * prof_steps / (prof[k]["ms"] * 1e-3) / 1e9, 1)} if k in kb and prof[k]["ms"] > 0 else {}),
 		}
 		for k in prof
-		if prof[k]["launches"] > 0
+		if prof[k]["launches"] > 0 and (k not in kb or kl.get(k, 1) > 0)
 	}
 
 	line = {

@@ -2484,17 +2484,20 @@ static int stage_chunk_cols(const slq_plan *p) {
 }
 
 // ||v||^2 of slot 0 -> nu_0, activity, first coefficients
-static int init_from_probes(slq_plan *p, int sphere) {
+// unit_entries: every entry of every probe is +-1 (Rademacher probes drawn by k_gen_probes): ||v||^2 = n is known, the norm sweep - one read of
+// the panel, 0.38 ms of configs[1]'s 55 - is skipped (r04; bitwise the same nu_0: the sweep's partial sums are exact integers)
+static int init_from_probes(slq_plan *p, int sphere, bool unit_entries = false) {
   hipStream_t st = p->ctx->stream;
   dim3 g(p->nblkS, p->NP);
-  PROFILED(p, SLQ_K_AXPY_NORM,
-           DISPATCH(p->dtype, p->LPR,
-                    (k_axpy_norm<F, L, 1><<<g, dim3(kBlock), 0, st>>>(p->n,
-                                        (F *)slot_ptr(p, 0), (const F *)nullptr,
-                                        (const double *)nullptr, p->part, p->bpad))));
+  if (!unit_entries)
+    PROFILED(p, SLQ_K_AXPY_NORM,
+             DISPATCH(p->dtype, p->LPR,
+                      (k_axpy_norm<F, L, 1><<<g, dim3(kBlock), 0, st>>>(p->n,
+                                          (F *)slot_ptr(p, 0), (const F *)nullptr,
+                                          (const double *)nullptr, p->part, p->bpad))));
   PROFILED(p, SLQ_K_FINALIZE,
            hipLaunchKernelGGL(k_fin_init, dim3((p->bpad + 63) / 64), dim3(kFinThreads), 0, st, p->st, p->part,
-                              p->nblkS, sphere, (double)p->n));
+                              unit_entries ? 0 : p->nblkS, sphere, (double)p->n));
   if (p->ring32_on) {  // vector 0 joins the fp32 archive
     switch (p->LPR) {
       case 64: k_archive32<64><<<g, dim3(kBlock), 0, st>>>(p->n, (const double *)slot_ptr(p, 0), p->ring32); break;
@@ -2595,7 +2598,7 @@ extern "C" int slq_plan_generate_probes(slq_plan *p, int pdf, uint64_t seed, uin
                     (k_gen_probes<F, L><<<g, dim3(256), 0, st>>>(p->n,
                                         (F *)slot_ptr(p, 0), pdf, seed, probe_offset, p->nprobes, p->op->inv_perm_d))));
   p->pdf_sphere = (pdf == SLQ_PDF_SPHERE);
-  return init_from_probes(p, p->pdf_sphere);
+  return init_from_probes(p, p->pdf_sphere, pdf == 0 && env_int("SLQ_KNOWN_NORM", 1) != 0);
 }
 
 // copy columns [c0, c0+nc) of `slot` to a host column-major array, optional per-column scale

@@ -1997,7 +1997,8 @@ __global__ __launch_bounds__(kFinThreads) void k_fin_init(StepState st, const do
                                                   int nblk, int sphere, double n_as_double) {
   __shared__ double red4[kFinThreads];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const double s = sum_partials(partN, nblk, st.bpad, col, red4);
+  // nblk = 0: Rademacher probes drawn on the device - ||v||^2 = n exactly (what the norm sweep sums to as well: integers are exact), no sweep
+  const double s = nblk > 0 ? sum_partials(partN, nblk, st.bpad, col, red4) : (col < st.nprobes ? n_as_double : 0.0);
   if ((threadIdx.x >> 6) == 0 && col < st.bpad) {
     const double nu0 = sqrt(s);
     const int act = (col < st.nprobes) && (nu0 > 0.0);

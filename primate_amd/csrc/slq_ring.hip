@@ -3,7 +3,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -c -DRING_F=double -DRING_LPR=32 -DRING_TAG=f64_l32 slq_ring.hip -o ring_f64_l32.o
 #include "slq_ring_api.h"
 #include "slq_ring.hpp"
+#ifndef SLQ_NO_FA  // (A/B builds of other ring geometries: the fused form needs four slots)
 #include "slq_ring_fa.hpp"
+#endif
 
 #ifndef RING_F
 #error "compile with -DRING_F=<double|float> -DRING_LPR=<64|32|16> -DRING_TAG=<f64_l64|...>"
@@ -67,6 +69,7 @@ int CAT(slq_ring_launch_, RING_TAG)(const RingArgs &a) {
   }
 }
 
+#ifndef SLQ_NO_FA
 // the update pass with the next step's alpha dot fused in (slq_ring_fa.hpp): whole-row panels only
 namespace {
 template <int RC> int launch_fa(const RingArgs &a) {
@@ -112,6 +115,14 @@ int CAT(slq_ring_fa_vgprs_, RING_TAG)(int rc) {
     default: return -1;
   }
 }
+
+#else
+int CAT(slq_ring_fa_launch_, RING_TAG)(const RingArgs &) { return -1; }
+int CAT(slq_ring_fa_vgprs_, RING_TAG)(int) { return -1; }
+namespace {
+template <int RC> hipError_t prepare_fa() { return hipSuccess; }
+}  // namespace
+#endif
 
 hipError_t CAT(slq_ring_prepare_, RING_TAG)() {
   hipError_t e = prepare<PASS_ALPHA, 0>();

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
     // line, 11-15 instructions per DMA - the narrow panels' alpha pass is bound by its loaders). All of a tile's reads go out
     // together in the read-ahead and are waited for once.
     constexpr int MAXU = (RG::kLines + RG::kLoaders - 1) / RG::kLoaders;  // lines of a tile per loader at most
-    static_assert(MAXU <= 18, "the read-ahead's operand list");
+    static_assert(R == 1 || MAXU <= 18, "the read-ahead's operand list");
     auto block0_addr = [&](int k) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R) * 256) + lane * 4; };
     auto lines_addr = [&](int k) { return (unsigned)(uintptr_t)(lds_int *)(stage + ((k % LAG) * R + g) * 256) + (kDescList + wave) * 4; };
     int d0cur = 0, dv = 0, ab = 0;

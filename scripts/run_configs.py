@@ -1,7 +1,7 @@
 """Full-size runs of BASELINE.json configs[2]-[4] on ONE GPU: wall time, probe-matvecs/s, and for the Lanczos loop of
 each the per-kernel roofline (HIP events on the library's stream, the same algorithmic-byte model as bench.py).
 
-    python scripts/run_configs.py [c3 c3x c4 c5 ...]   ->  gpurun_out/r03_configs.json  (copied to profiles/ when judged)
+    python scripts/run_configs.py [c3 c3x c4 c5 ...]   ->  gpurun_out/<RUN_TAG, default r04>_configs.json  (copied to profiles/ when judged)
 
 c3  = configs[2] operator, hutch (quadrature) at orth 0 and 3          c3x = configs[2] as worded: xtrace, 512 vectors
 c4  = configs[3]: diag(exp(-t L)), 126^3 7-point grid, fp32, k = 50, 1024 probes
@@ -25,8 +25,10 @@ from conftest import laplacian_3d  # noqa: E402
 from primate_amd.engine import DeviceOperator, DiagAccumulator, LanczosPlan  # noqa: E402
 
 which = sys.argv[1:] or ["c3", "c3x", "c4", "c5"]
-out_path = ROOT / "gpurun_out" / "r03_configs.json"
+out_path = ROOT / "gpurun_out" / f"{os.environ.get('RUN_TAG', 'r04')}_configs.json"
 out = json.loads(out_path.read_text()) if out_path.exists() else {}
+if out.get("_meta", {}).get("kernel_sha256") not in (None, bench.kernel_sources_sha256()):
+	out = {}  # (entries measured on other kernel sources are not carried along)
 out["_meta"] = {"kernel_sha256": bench.kernel_sources_sha256(), "peak_GBps": bench.HBM_PEAK_GBS,
                 "note": "per-kernel ms are HIP events on the library's stream over the timed batches; alg_GBps = bench.kernel_bytes / ms"}  # fmt: skip
 
@@ -35,7 +37,8 @@ def lanczos_roofline(plan, A, b, deg, orth, batches):
 	"""Per-kernel-class time and algorithmic GB/s of the Lanczos loop, from the plan's HIP-event profile."""
 	info = plan.describe()
 	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
-	kb, kl = bench.kernel_bytes(n, nnz, s, b, info["panel_width"], deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]))
+	## (every config here draws its probes on the device; Rademacher ones need no norm sweep since r04)
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, info["panel_width"], deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]), norm_sweep=False)
 	prof = plan.profile_read(reset=True)
 	rows = {}
 	for k, v in prof.items():

@@ -21,7 +21,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def kernel_sources_sha256():
 	"""Same digest as bench.py:kernel_sources_sha256 - the bench line quotes a traffic figure only when it matches."""
 	h = hashlib.sha256()
-	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq.hip"):
+	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq_ring_fa.hpp", "primate_amd/csrc/slq.hip"):
 		h.update((ROOT / f).read_bytes())
 	return h.hexdigest()
 
@@ -49,11 +49,13 @@ def classify(name: str, orth: int):
 
 summary = {"_meta": {"tag": os.path.basename(os.path.normpath(out_dir)), "kernel_sha256": kernel_sources_sha256(),
                      "collected_by": "scripts/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass)"}}
-for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 6), ("lap2d_1000", 30), ("lap3d_100", 3), ("lap3d_100", 0)):
+for workload, orth, P in (("lap2d_1000", 3, 256), ("lap2d_1000", 0, 256), ("lap2d_1000", 6, 256), ("lap2d_1000", 30, 256), ("lap3d_100", 3, 256), ("lap3d_100", 0, 256),
+                          ("lap3d_100", 30, 256), ("lap2d_1000", 3, 64), ("lap3d_100", 3, 64)):
 	per = defaultdict(lambda: defaultdict(list))
 	names = {}
+	sfx = "" if P == 256 else f"_p{P}"
 	for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-		for f in glob.glob(f"{out_dir}/pmc_{counter}_{workload}_orth{orth}/**/*counter_collection.csv", recursive=True):
+		for f in glob.glob(f"{out_dir}/pmc_{counter}_{workload}_orth{orth}{sfx}/**/*counter_collection.csv", recursive=True):
 			with open(f) as fh:
 				for row in csv.DictReader(fh):
 					if row.get("Counter_Name") != counter:
@@ -78,5 +80,5 @@ for workload, orth in (("lap2d_1000", 3), ("lap2d_1000", 0), ("lap2d_1000", 6), 
 			"hbm_bytes_per_launch": int((2 * fa + wa) * 1024),
 			"correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section; check rows: gen_probes writes and probe_norm reads exactly one panel sweep (s*n*b bytes)",
 		}
-	summary[f"{workload}/P256/k30/orth{orth}"] = entry
+	summary[f"{workload}/P{P}/k30/orth{orth}"] = entry
 json.dump(summary, sys.stdout, indent=1)
