@@ -3366,6 +3366,7 @@ static int update_chunk_cols(const slq_plan *p) {
 // w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
 // axpy: the first chunk also applies the three-term step's `w -= cB W_c` (the dots sweeps ran in mode 2 and stored nothing)
 static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r, bool axpy, int klass) {
+  if (axpy && (istart != 0 || r < 1)) return fail(SLQ_EINVAL, "internal: the deferred axpy rides on column 0 of the first update chunk");
   hipStream_t st = p->ctx->stream;
   const int V = p->dtype == SLQ_F64 ? 2 : 4;
   const int kUpdChunk = update_chunk_cols(p);
@@ -3375,7 +3376,7 @@ static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r, boo
     const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
     PROFILED(p, klass,
              DISPATCH(p->dtype, p->LPR,
-                      (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r), axpy && i0 == istart))));  // last chunk: w is final
+                      (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r), axpy && i0 == 0))));  // last chunk: w is final; (axpy: column 0 of the chunk must be W_c)
   }
   return SLQ_OK;
 }

@@ -1733,7 +1733,6 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
   __syncthreads();
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
-  const F *Wc = ring + (int64_t)(j % S) * slot_stride + poff;
   VF cb = (VF)(F)0;
   if (coefB) {
 #pragma unroll
@@ -1752,16 +1751,19 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       ro[u] = (int64_t)(row < n ? row : 0) * PW;
       w[u] = stream_load<SLQ_SWEEP_LDW>((const VF *)(W + ro[u]));
     }
-    if (coefB) {
-#pragma unroll
-      for (int u = 0; u < UR; ++u) w[u] -= cb * *(const VF *)(Wc + ro[u]);  // (the row is read again as column 0 below: an L1 hit)
-    }
     for (int i = 0; i < r; ++i) {
       const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
       const VF gm = *(const VF *)(gl + i * PW + cl * V);
       VF x[UR];
 #pragma unroll
       for (int u = 0; u < UR; ++u) x[u] = *(const VF *)(U + ro[u]);
+      if (coefB && i == 0) {
+        // the deferred three-term axpy on the row the sweep holds anyway: column 0 of the first chunk IS W_c (the host passes coefB with
+        // i0 = 0 only). First cB, then gamma_0, as the stored form did it: bitwise the same w. (A load of its own for this term - the first
+        // version - made the sweep 4-6 % slower: two requests for one row.)
+#pragma unroll
+        for (int u = 0; u < UR; ++u) w[u] -= cb * x[u];
+      }
 #pragma unroll
       for (int u = 0; u < UR; ++u) w[u] -= gm * x[u];
     }
