@@ -69,7 +69,7 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 FUSED_MAX_R = 8  # slq_kernels.hpp:kFusedMaxR
 
 
-def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True, norm_sweep=True):
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True, norm_sweep=True, last_nostore=True):
 	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each
 	vector panel a kernel touches is read or written once, the CSR arrays once per panel of `pw`
 	probes. Launch sequences per Lanczos step (slq.hip:enqueue_run; `LanczosPlan.describe()["sequence"]`):
@@ -93,13 +93,15 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 	for j in range(deg):
 		r = 0 if orth == 0 else min(j + 1, orth)
 		rd = (1 if j == 0 else 2) + max(r - 2, 0)  # q_c (gather), q_p, ring columns beyond those two
+		## the fused update pass of a run's LAST step stores nothing (r04: W_deg is never read, only its norm; plans without a kept basis)
+		wr = 0 if (last_nostore and j == deg - 1) else 1
 		if sequence == "fused_gram" and 1 <= r <= FUSED_MAX_R:
 			## alpha-only pass (q_c alone: the -beta q_c.q_p part and every projection come from Gram rows the update passes take) and
 			## the update pass; steps with r = 0 never occur in this sequence (orth >= 1), deeper ones fall through to the sweeps
 			nz = (nnz + n) // 2 if upper_alpha else nnz
 			out["spmm_3term"] += npan * ((s + 4) * nz + 4 * (n + 1)) + vec
 			launches["spmm_3term"] += 1
-			out["reorth_update"] += csr + (rd + 1) * vec
+			out["reorth_update"] += csr + (rd + wr) * vec
 			launches["reorth_update"] += 1
 			continue
 		if sequence in ("fused", "fused_gram") and r <= FUSED_MAX_R:
@@ -113,7 +115,7 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 				out["reorth_dot"] += csr + rd * vec
 				launches["reorth_dot"] += 1
 			k = "reorth_update" if r > 0 else "axpy_norm"
-			out[k] += csr + (rd + 1) * vec
+			out[k] += csr + (rd + wr) * vec
 			launches[k] += 1
 			continue
 		if sequence == "fused_stored_u" and 1 <= r <= FUSED_MAX_R:
@@ -268,7 +270,8 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 	info = plan.describe()  # panel geometry and launch sequence the library chose
 	pw, fused = info["panel_width"], not info["sequence"].startswith("sweeps")
 	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]),
-	                      norm_sweep=os.environ.get("SLQ_KNOWN_NORM", "1") == "0")  # (the bench draws Rademacher probes on the device)
+	                      norm_sweep=os.environ.get("SLQ_KNOWN_NORM", "1") == "0",  # (the bench draws Rademacher probes on the device)
+	                      last_nostore=os.environ.get("SLQ_LAST_STORE", "0") == "0")
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)
 	launches = prof[dom]["launches"]

@@ -248,6 +248,7 @@ struct slq_plan {
   int fa_rounds = 0;
   int part_maxblk = 0;        // blocks per slab of `part`
   bool launch_error = false;  // a launcher declined (mis-dispatch): the run is invalid (enqueue_run)
+  bool last_nostore = true;   // the update pass of a run's last step does not store W_deg (plans without a kept basis; SLQ_LAST_STORE=1 stores)
 };
 
 // SLQ_TILES: 0 none, 1 workgroup tiles landed behind barriers (k_csr_tile_pass), 2 tiles fed through a ring of LDS slots by
@@ -2122,6 +2123,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   // the Gram sequence on the generic passes (no tiles, or a plan whose panels the tiles do not serve): the dots pass - a third to a half of every
   // step's bytes - is gone there as well. Not for operators whose gathers are the cost (random graphs keep the stored-u sequence: it gathers once,
   // the Gram sequence twice) - enqueue_run decides that per step exactly as before.
+  p->last_nostore = env_int("SLQ_LAST_STORE", 0) == 0;
   p->gram_csr = op->kind == OP_CSR && p->ringR == 0 && op->rowptr_u != nullptr && p->sw.merged && !p->sw.mgs && p->sw.nt && env_int("SLQ_GRAM", 1) != 0 && env_int("SLQ_GRAM_CSR", 1) != 0;
   {
     // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
@@ -2837,8 +2839,9 @@ static inline void launch_csr_pass(bool pipe_on, dim3 grid, size_t lds, hipStrea
 
 template <typename F, int L, int RC> static inline void launch_csr_updateg_rc(slq_plan *p, bool pipe_on, dim3 grid, size_t lds, hipStream_t st, int j) {
   const slq_operator *op = p->op;
+  const int xt = (j == p->deg - 1 && !p->keep_basis && p->last_nostore) ? 16 : 0;  // (the run's last step: W_deg is not stored)
   launch_csr_pass<F, L, PASS_UPDATEG, 1, RC>(pipe_on, grid, lds, st, p->n, op->rowptr, op->colind, (const F *)op->vals, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
-                                             p->st.coefB, p->st.gamma, p->part, p->bpad, 0);
+                                             p->st.coefB, p->st.gamma, p->part, p->bpad, xt);
 }
 
 // the same pass on workgroup tiles (wide panels only; slq_kernels.hpp: k_csr_tile_pass)
@@ -2899,7 +2902,9 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.gamma = p->st.gamma;
   a.part = p->part;
   a.bpad = p->bpad;
-  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0) | ((upper && p->rs_u_padded) ? 8 : 0);  // bit 3: padded rows
+  // bit 4: the LAST step of a run whose basis is not kept stores nothing - W_deg is never read (lanczos.h:139-142 takes its norm and breaks); SLQ_LAST_STORE=1 keeps the store
+  const bool last_nostore = (pass == PASS_UPDATE || pass == PASS_UPDATEG) && j == p->deg - 1 && !p->keep_basis && p->last_nostore;
+  a.xt = xt | (((pass == PASS_UPDATE || pass == PASS_UPDATEG) && p->sw.ring_rev) ? 4 : 0) | ((upper && p->rs_u_padded) ? 8 : 0) | (last_nostore ? 16 : 0);  // bit 3: padded rows
   a.fail = p->ring_fail_d;
   a.dbg = pass == env_int("SLQ_DEBUG_PASS", PASS_ADOTS) ? debug_times_buffer() : nullptr;  // (diagnostic builds: the pass whose time line is stamped)
   const bool d = p->dtype == SLQ_F64;
@@ -3128,8 +3133,10 @@ static int enqueue_run(slq_plan *p, double rtol, int fused_mode, bool nt) {
       }
       }
       const size_t ldsU = lds0 + fused_pad;
+      // (generic passes: the run's last step does not store W_deg; the ring-fed ones add the bit themselves, launch_ring_gen; the older tiled kernels store)
+      const int xt_uu = xt_u | ((!tiled && j == deg - 1 && !p->keep_basis && p->last_nostore && !stored_u) ? 16 : 0);
       PROFILED(p, (r == 0 ? SLQ_K_AXPY_NORM : SLQ_K_REORTH_UPD),
-               { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_u); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_u); });
+               { if (nt) CSR_PASS(PASS_UPDATE, 1, 1, 0, r, ldsU, xt_uu); else CSR_PASS(PASS_UPDATE, 0, 0, 0, r, ldsU, xt_uu); });
 #undef CSR_PASS
 #undef CSR_PASS_RC
       nblk_last = tiled ? p->nblkT : p->nblkU;

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
   const int stored = (xt & 2) != 0;
+  const int nostore = (xt >> 4) & 1;  // update passes: the new vector is not stored (a run's last step without a kept basis, r04)
   xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wc = ring + (int64_t)(j % S) * slot_stride + poff;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_csr_pass(
           if constexpr (RC > 1) w -= gm[1] * xp;
 #pragma unroll
           for (int i = 2; i < RC; ++i) w -= gm[i] * u[i - 2];
-          stream_store<NTP>((VF *)(wn + ro), w);
+          if (!nostore) stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += w * w;
           if constexpr (PASS == PASS_UPDATEG) {
             // Gram sequence outside the ring-fed tiles (r04): the new vector against every ring column the pass

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
   const int panel = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
   const int padded_rows = (xt >> 3) & 1;  // the stream's rows are padded to whole chunks of four entries (slq.hip: build_ring_stream)
+  const int nostore = (xt >> 4) & 1;      // update passes: the new vector is not stored (a run's LAST step without a kept basis: only its norm is ever used, r04)
   xt &= 1;
   const int first = (j == 0) || (PASS == PASS_ALPHA && xt);
   const F *wcl = ring + (int64_t)(j % S) * slot_stride + poff;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_pass(
           if constexpr (RC > 1) w -= gm[1] * xp;
 #pragma unroll
           for (int q = 2; q < RC; ++q) w -= gm[q] * u_in[q - 2];
-          stream_store<NTP>((VF *)(wn + ro), w);
+          if (!nostore) stream_store<NTP>((VF *)(wn + ro), w);
           acc1 += w * w;
           if constexpr (PASS == PASS_UPDATEG) {
             // the new vector against every ring column the pass has in registers: the Gram row W_{j+1} . W_{j-q} from which

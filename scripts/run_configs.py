@@ -38,7 +38,8 @@ def lanczos_roofline(plan, A, b, deg, orth, batches):
 	info = plan.describe()
 	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
 	## (every config here draws its probes on the device; Rademacher ones need no norm sweep since r04)
-	kb, kl = bench.kernel_bytes(n, nnz, s, b, info["panel_width"], deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]), norm_sweep=False)
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, info["panel_width"], deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]), norm_sweep=False,
+	                            last_nostore=not plan.keep_basis)
 	prof = plan.profile_read(reset=True)
 	rows = {}
 	for k, v in prof.items():
