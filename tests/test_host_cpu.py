@@ -168,9 +168,14 @@ def test_bench_byte_model():
 	assert kb["reorth_update"] == sum(min(j + 1, 30) + 2 for j in range(30)) * vec
 	## fused passes (r <= 4): alpha pass reads 1 panel over the upper triangle, update pass reads 2 (+r-2) and writes 1
 	csr_u = 2 * (12 * ((nnz + n) // 2) + 4 * (n + 1))
-	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=True)
+	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=True, last_nostore=False)
 	assert kl == {"spmm_3term": 30, "axpy_norm": 31, "reorth_dot": 0, "reorth_update": 0}
 	assert kb["spmm_3term"] == 30 * csr_u + 30 * vec and kb["axpy_norm"] == vec + 30 * csr + (2 + 29 * 3) * vec
+	## r04: the last step's update pass stores nothing (W_deg is never read), and Rademacher probes drawn on the device need no norm sweep
+	kb2, kl2 = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=True)
+	assert kb2["axpy_norm"] == kb["axpy_norm"] - vec and kl2 == kl
+	kb3, kl3 = bench.kernel_bytes(n, nnz, s, b, 128, 30, 0, fused=True, norm_sweep=False)
+	assert kb3["axpy_norm"] == kb2["axpy_norm"] - vec and kl3["axpy_norm"] == 30
 	kb, kl = bench.kernel_bytes(n, nnz, s, b, 128, 30, 3, fused=True)
 	assert kl["reorth_dot"] == 30 and kb["reorth_dot"] == 30 * csr + (1 + 2 + 28 * 3) * vec
 	## deeper reorthogonalisation falls back to the store-and-revisit sweeps once r_j > 4
