@@ -113,6 +113,7 @@ struct slq_operator {
   char *tile_rec = nullptr;      // the tiles' CSR records
   int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
   char *tile_rec_u = nullptr;
+  int32_t xcd_tile_u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // tile ranges of the upper-triangle stream, whose tiles are runs of the base tiles (regroup_upper_tiles, r04)
   int tile_max_lines_u = 0;        // longest line list of a tile in that stream (short lists: a ring geometry with one slot more)
   bool tile_u_padded = false;      // ... with every row's entries padded to a multiple of four (build_ring_stream: pad_rows)
   double upper_per_row = 0.0;      // distinct panel rows per row that stream lands (what decides whether the alpha-only pass takes it)
@@ -241,6 +242,7 @@ struct slq_plan {
   const char *rs_rec, *rs_rec_u;
   bool rs_u_padded;            // ... whose rows are padded to whole chunks of four entries (the alpha-only pass's branch-free consumer)
   int32_t rs_xcd[9];
+  int32_t rs_xcd_u[9];         // ... and of the upper-triangle stream (its tiles are runs of the base tiles)
   bool ring_staged;           // the alpha-only pass's loaders go through registers (SLQ_RING_STAGED; slq_ring.hpp: GEO 1)
   // the update pass takes the next step's alpha dot a fixed lag of tile rounds behind its write front (slq_ring_fa.hpp; SLQ_FUSED_ALPHA):
   bool fa_on = false;
@@ -890,6 +892,65 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
   if (!ok) throw std::bad_alloc();
 }
 
+// Tiles of the upper-triangle stream (the alpha-only pass, r04). That pass lands 31-32 GB/s per CU by LDS-DMA whatever the operator (configs[1]: 1.64 KiB per row,
+// 0.40 ms; 100^3: 2.65 KiB per row, 0.65 ms) - the DMA path's own cadence - so what shortens it is fewer landed lines per row. The base tiles are cut to what a slot
+// holds of FULL rows; over the upper triangle the same rows need two thirds of the lines, so consecutive base tiles of a chunk - neighbours in the sweep, which share
+// halo - are joined while the run keeps to kRingTileRows rows, kRingTileCols distinct lines (rows and upper columns) and kRingTileNnz padded entries: 100^3, 118,940 ->
+// 107,848 tiles, alpha pass 0.652 -> 0.607 ms. (Cutting the chunk's rows anew, row by row, to the same caps gives 12.9-row tiles that straddle cluster boundaries and
+// land MORE lines per row, 2.65 against 2.47: 0.82 ms. Not kept.) Tiles stay contiguous row ranges of one XCD chunk; kernel and stream format do not change.
+static void regroup_upper_tiles(const int32_t *urp, const int32_t *uci, const std::vector<int32_t> &tile_row, const int32_t xcd_tile[9],
+                                std::vector<int32_t> &tile_row_u, int32_t xcd_tile_u[9]) {
+  auto padded = [](int32_t cnt) { return std::max<int32_t>(4, (cnt + 3) / 4 * 4); };
+  // every chunk on its own (in parallel): consecutive base tiles - neighbours in the sweep - joined while the run keeps to the caps
+  std::vector<int32_t> cuts[8];
+  const bool ok = parallel_pieces(8, 8, [&](int, int64_t x0, int64_t x1) {
+    for (int64_t x = x0; x < x1; ++x) {
+      std::vector<int32_t> &out = cuts[x];
+      int32_t lines[2 * kRingTileCols + 16];
+      int nl = 0, rows = 0, nz = 0;
+      for (int32_t t = xcd_tile[x]; t < xcd_tile[x + 1]; ++t) {
+        const int32_t r0 = tile_row[(size_t)t], r1 = tile_row[(size_t)t + 1];
+        // what this base tile would add to the run: its rows and their upper columns, unless already listed
+        int32_t fresh[kRingTileCols + 16];
+        int nf = 0;
+        int32_t pz = 0;
+        auto consider = [&](int32_t c) {
+          for (int q = 0; q < nl; ++q)
+            if (lines[q] == c) return;
+          for (int q = 0; q < nf; ++q)
+            if (fresh[q] == c) return;
+          if (nf < kRingTileCols + 16) fresh[nf++] = c;
+        };
+        for (int32_t r = r0; r < r1; ++r) {
+          consider(r);
+          for (int32_t q = urp[r]; q < urp[r + 1]; ++q) consider(uci[q]);
+          pz += padded(urp[r + 1] - urp[r]);
+        }
+        if (rows > 0 && (rows + (r1 - r0) > kRingTileRows || nl + nf > kRingTileCols || nz + pz > kRingTileNnz)) {
+          nl = rows = nz = 0;  // cut: this base tile opens the next run (its own lines: everything it lists)
+          nf = 0;
+          for (int32_t r = r0; r < r1; ++r) {
+            consider(r);
+            for (int32_t q = urp[r]; q < urp[r + 1]; ++q) consider(uci[q]);
+          }
+        }
+        if (rows == 0) out.push_back(r0);
+        for (int q = 0; q < nf && nl < 2 * kRingTileCols + 16; ++q) lines[nl++] = fresh[q];
+        rows += r1 - r0;
+        nz += pz;
+      }
+    }
+  });
+  if (!ok) throw std::bad_alloc();
+  tile_row_u.clear();
+  for (int x = 0; x < 8; ++x) {
+    xcd_tile_u[x] = (int32_t)tile_row_u.size();
+    tile_row_u.insert(tile_row_u.end(), cuts[x].begin(), cuts[x].end());
+  }
+  xcd_tile_u[8] = (int32_t)tile_row_u.size();
+  tile_row_u.push_back(tile_row.back());
+}
+
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
 // upper entries doubled and return true. Row ranges in parallel: every off-diagonal entry (i, j) looks its mirror (j, i)
 // up by bisection in row j (rows are sorted - checked on the way) and compares the values; the upper entries are then
@@ -1322,7 +1383,20 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         // the same tiles over the upper triangle (doubled off-diagonals), for the alpha-only pass: a tile's image then holds its
         // own rows and the neighbours of HIGHER index only - about half the halo, and the pass is bound by what it lands by DMA
         int mxu = 0;
-        build_tile_meta(n, urp.data(), uci.data(), tile_row, tpu, tcu, lcu, siu, &mxu);
+        // (its own, longer tiles: runs of the base tiles - the pass pays per tile, regroup_upper_tiles; SLQ_RING_UPPER_REGROUP=0 keeps the base tiles)
+        std::vector<int32_t> tile_row_u;
+        // (not where the base tiles are as tall as a tile gets - a 5-point grid's 13.9 of 14 rows: nothing to join, 10-20 ms of host time saved)
+        const bool tall_already = (double)n / (double)(tile_row.size() - 1) > 0.8 * kRingTileRows;
+        if (env_int("SLQ_RING_UPPER_REGROUP", 1) != 0 && !tall_already) {
+          regroup_upper_tiles(urp.data(), uci.data(), tile_row, xcd_tile, tile_row_u, op->xcd_tile_u);
+        } else {
+          tile_row_u = tile_row;
+          for (int x = 0; x < 9; ++x) op->xcd_tile_u[x] = xcd_tile[x];
+        }
+        if (env_int("SLQ_DEBUG", 0) != 0)
+          fprintf(stderr, "[slq] tiles: upper-triangle stream on %zu tiles of %.2f rows (base: %zu of %.2f)\n", tile_row_u.size() - 1, (double)n / (double)(tile_row_u.size() - 1),
+                  tile_row.size() - 1, (double)n / (double)(tile_row.size() - 1));
+        build_tile_meta(n, urp.data(), uci.data(), tile_row_u, tpu, tcu, lcu, siu, &mxu);
         clk.lap("  upper tile lists");
         // Worth it while the tiles land at most kTileAlphaColsPerRow panel rows per row (r03, scalar-descriptor loaders and the
         // padded-row consumer of slq_ring.hpp: 5-point grid, 1.5 rows per row: 0.40 against 0.51 ms for the generic pass; 7-point
@@ -1336,8 +1410,8 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
         // 0.25 against 0.35 ms for the generic upper-triangle pass)
         if (upper_per_row <= kTileAlphaMergedColsPerRow) {
           bool pad = env_int("SLQ_RING_PAD_ROWS", 1) != 0;
-          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
-          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
+          if (dtype == SLQ_F64) build_ring_stream<double>(1, urp.data(), (const double *)uva.data(), tile_row_u, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
+          else build_ring_stream<float>(1, urp.data(), (const float *)uva.data(), tile_row_u, tpu, tcu, lcu, siu, desc_u, rec_u, &pad);
           op->tile_u_padded = pad;
           clk.lap("  upper tile stream");
           te = hipMalloc((void **)&op->tile_desc_u, desc_u.size() * 4);
@@ -2086,7 +2160,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
     p->rs_rec = p->rs_rec_u = nullptr;
     p->rs_u_padded = false;
     p->ring_staged = false;
-    for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x];
+    for (int x = 0; x < 9; ++x) p->rs_xcd[x] = op->tiles.xcd_tile[x], p->rs_xcd_u[x] = op->xcd_tile_u[x];
     if (op->kind == OP_CSR && op->tiles.tile_ptr && p->sw.tiles) {
       if (p->LPR == 64) {
         p->ringR = 1;
@@ -2104,7 +2178,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
         p->ring_gen = true;
         p->ring_deep = env_int("SLQ_RING_DEEP", 1) != 0;
         p->rs_desc = m.desc, p->rs_rec = m.rec, p->rs_desc_u = m.desc_u, p->rs_rec_u = m.rec_u, p->rs_u_padded = m.u_padded;
-        for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x];
+        for (int x = 0; x < 9; ++x) p->rs_xcd[x] = m.xcd_tile[x], p->rs_xcd_u[x] = m.xcd_tile[x];  // (merged streams: one partition for both)
       }
       // alpha-only pass: LDS-DMA loaders everywhere since their r03 rewrite (merged tiles: a lane reads its lines' sources straight
       // out of the staged descriptor - 100^3, 64 probes 0.230 -> 0.187 ms against the register-staged loaders that had been the
@@ -2856,6 +2930,8 @@ static inline void launch_tile_pass(slq_plan *p, dim3 grid, size_t lds, hipStrea
         // the ring-fed variant: flag words and descriptor staging + kRingSlots slots; 16 waves per workgroup
         const size_t lds_ring = kRingHeadBytes + (size_t)kRingSlots * (kRingTileCols * 1024 + kRingMetaBytes);
         const bool upper = PASS == PASS_ALPHA && p->rs_desc_u != nullptr && p->sw.ring_alpha == 2;
+        if (upper)
+          for (int x = 0; x < 9; ++x) xr.first[x] = p->rs_xcd_u[x];
         k_csr_ring_pass<F, PASS, LP, RC><<<grid, dim3(kRingBlock), lds_ring, st>>>(p->n, upper ? p->rs_desc_u : op->tile_desc, upper ? p->rs_rec_u : op->tile_rec, xr, (F *)p->ring, p->slot_stride, p->S, j, p->st.coefA,
                                                                                p->st.coefB, p->st.gamma, p->part, p->bpad,
                                                                                xt | ((PASS == PASS_UPDATE && p->sw.ring_rev) ? 4 : 0), p->ring_fail_d);
@@ -2892,7 +2968,7 @@ static int launch_ring_gen(slq_plan *p, int pass, int rc, dim3 grid, hipStream_t
   a.n = p->n;
   a.desc = upper ? p->rs_desc_u : p->rs_desc;
   a.rec = upper ? p->rs_rec_u : p->rs_rec;
-  for (int x = 0; x < 9; ++x) a.xr.first[x] = p->rs_xcd[x];
+  for (int x = 0; x < 9; ++x) a.xr.first[x] = upper ? p->rs_xcd_u[x] : p->rs_xcd[x];
   a.ring = p->ring;
   a.slot_stride = p->slot_stride;
   a.S = p->S;
