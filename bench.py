@@ -69,7 +69,7 @@ def contract_bytes_per_probe_matvec(n, nnz, s, b, j, orth):
 FUSED_MAX_R = 8  # slq_kernels.hpp:kFusedMaxR
 
 
-def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True, norm_sweep=True, last_nostore=True):
+def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=None, upper_alpha=True, norm_sweep=True, last_nostore=True, sweep_live_frac=1.0):
 	"""Algorithmic HBM bytes of every launch of one `run`, per kernel class: each
 	vector panel a kernel touches is read or written once, the CSR arrays once per panel of `pw`
 	probes. Launch sequences per Lanczos step (slq.hip:enqueue_run; `LanczosPlan.describe()["sequence"]`):
@@ -141,7 +141,9 @@ def kernel_bytes(n, nnz, s, b, pw, deg, orth, chunk=16, fused=True, sequence=Non
 				## update sweep): w + the chunk's columns, and W_c once more in later chunks; the archive form stores in its first chunk
 				out["reorth_dot"] += (cols(i0, i0 + rc) + ((2 if i0 == 0 else 1) if half else (1 if i0 == 0 else 2))) * vec
 				launches["reorth_dot"] += 1
-			out["reorth_update"] += (cols(0, r) + 2 + (0.5 if half else 0.0)) * vec
+			## (the update sweep reads a ring column only when some probe of the panel projects on it: sweep_live_frac = columns read / columns
+			## offered, measured - LanczosPlan.sweep_columns(); the fp32-archive form reads them all)
+			out["reorth_update"] += (cols(0, r) * (1.0 if half else sweep_live_frac) + 2 + (0.5 if half else 0.0)) * vec
 			launches["reorth_update"] += 1
 	return out, launches
 
@@ -230,6 +232,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 
 	for it in range(warmup):
 		step(it)
+	plan.sweep_columns(reset=True)
 	## per-kernel HIP events over the timed region (the roofline object needs them); BENCH_NO_PROFILE=1 times the
 	## same steps without them (hipGraph replay) to show what the instrumentation costs
 	plan.profile_enable(profiled)
@@ -268,10 +271,12 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 
 	## ---- roofline of the dominant kernel (HIP events on the kernels' own stream) --------------
 	info = plan.describe()  # panel geometry and launch sequence the library chose
+	cols_read, cols_offered = plan.sweep_columns(reset=True)  # (deep windows: ring columns the update sweeps read / were offered)
 	pw, fused = info["panel_width"], not info["sequence"].startswith("sweeps")
 	kb, kl = kernel_bytes(n, nnz, s, P, pw, deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]),
 	                      norm_sweep=os.environ.get("SLQ_KNOWN_NORM", "1") == "0",  # (the bench draws Rademacher probes on the device)
-	                      last_nostore=os.environ.get("SLQ_LAST_STORE", "0") == "0")
+	                      last_nostore=os.environ.get("SLQ_LAST_STORE", "0") == "0",
+	                      sweep_live_frac=(cols_read / cols_offered) if cols_offered else 1.0)
 	cand = {k: prof[k]["ms"] for k in kb if prof[k]["launches"] > 0}
 	dom = max(cand, key=cand.get)
 	launches = prof[dom]["launches"]
@@ -310,6 +315,7 @@ def measure(ctx, workload, dtype, P, deg_req, orth_req, steps, warmup, fun, rank
 			"panel_width": info["panel_width"], "create_s": round(create_s, 4), "plan_s": round(plan_s, 4),
 			"parallelism": f"probe-sharded x{world}, operator replicated", "fused_passes": bool(fused), "plan": info,
 			"kernel_events_in_timed_region": bool(profiled),
+			"update_sweep_columns": {"read": cols_read, "offered": cols_offered},
 		},
 		"trace_estimates_per_s": round(P_global * steps / elapsed, 1),
 		"estimate": float(estimate),

@@ -283,6 +283,10 @@ typedef struct {
   int64_t launches[SLQ_K_COUNT];
 } slq_profile;
 int slq_plan_profile_enable(slq_plan *plan, int enable);
+/* Byte accounting of the deep-window update sweep (orth > 8), which reads a ring column only when some probe of the panel has a non-zero projection on it - the
+ * reference skips a projection per probe below its threshold, src/primate/include/lanczos.h:62 -: columns read / columns offered, summed over launches and panels
+ * since the last reset. Synchronises. */
+int slq_plan_sweep_columns(slq_plan *plan, uint64_t *read, uint64_t *offered, int reset);
 int slq_plan_profile_read(slq_plan *plan, slq_profile *out, int reset);
 
 /* Failure reporting of the ring-fed tile pass (k_csr_ring_pass). Every wait inside that kernel is bounded; a workgroup

@@ -96,6 +96,7 @@ _SIGNATURES = {
 	"slq_diag_update": (C.c_int, [_P, _P, C.c_int, _P]),
 	"slq_diag_get": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int64)]),
 	"slq_plan_profile_enable": (C.c_int, [_P, C.c_int]),
+	"slq_plan_sweep_columns": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
 	"slq_plan_profile_read": (C.c_int, [_P, C.POINTER(SlqProfile), C.c_int]),
 	"slq_quad_batch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, _P, _P]),
 	"slq_eigh_tridiag_batch": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -250,6 +250,8 @@ struct slq_plan {
   int fa_rounds = 0;
   int part_maxblk = 0;        // blocks per slab of `part`
   bool launch_error = false;  // a launcher declined (mis-dispatch): the run is invalid (enqueue_run)
+  bool sweep_skip = true;     // the update sweep does not read ring columns whose coefficient is zero for every probe of the panel (SLQ_SWEEP_SKIP=0: reads them all)
+  unsigned long long *sweep_cols_d = nullptr;  // {ring columns the update sweeps read, columns they were offered}, summed over launches and panels (slq_plan_sweep_columns)
   bool last_nostore = true;   // the update pass of a run's last step does not store W_deg (plans without a kept basis; SLQ_LAST_STORE=1 stores)
 };
 
@@ -2073,6 +2075,7 @@ extern "C" int slq_plan_destroy(slq_plan *p) {
   if (p->scal) hipFree(p->scal);
   if (p->part) hipFree(p->part);
   if (p->fa_cnt) hipFree(p->fa_cnt);
+  if (p->sweep_cols_d) hipFree(p->sweep_cols_d);
   if (p->quad_d) hipFree(p->quad_d);
   if (p->st.active) hipFree(p->st.active);
   ctx_release(p->ctx);
@@ -2198,6 +2201,7 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   // step's bytes - is gone there as well. Not for operators whose gathers are the cost (random graphs keep the stored-u sequence: it gathers once,
   // the Gram sequence twice) - enqueue_run decides that per step exactly as before.
   p->last_nostore = env_int("SLQ_LAST_STORE", 0) == 0;
+  p->sweep_skip = env_int("SLQ_SWEEP_SKIP", 1) != 0;
   p->gram_csr = op->kind == OP_CSR && p->ringR == 0 && op->rowptr_u != nullptr && p->sw.merged && !p->sw.mgs && p->sw.nt && env_int("SLQ_GRAM", 1) != 0 && env_int("SLQ_GRAM_CSR", 1) != 0;
   {
     // tiled passes: as many workgroups resident per CU as their LDS images admit (2 x 72 KiB by default), the same number
@@ -2232,6 +2236,8 @@ extern "C" int slq_plan_create(slq_context *ctx, slq_operator *op, int nprobes, 
   if (e == hipSuccess && p->ring32_on) e = hipMalloc((void **)&p->ring32, ring32_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&p->scal, nscal * 8);
   if (e == hipSuccess) e = hipMalloc((void **)&p->part, npart * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->sweep_cols_d, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(p->sweep_cols_d, 0, 2 * sizeof(unsigned long long));
   if (e == hipSuccess && p->fa_on) e = hipMalloc((void **)&p->fa_cnt, ((size_t)p->NP * 8 * p->fa_rounds + 8) * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void **)&p->st.active, bp * 2 * sizeof(int) + 16);
   if (e == hipSuccess) e = hipMalloc((void **)&p->quad_d, (bp + 2 * bp * (size_t)deg) * 8);
@@ -2534,6 +2540,20 @@ extern "C" int slq_plan_describe(const slq_plan *p, slq_plan_info *out) {
   out->far_per_row = p->op->far_per_row;
   out->tiles = plan_tiled(p) ? (p->op->tiles_ringed ? 2 : 1) : 0;
   out->fused_alpha = (p->fa_on && plan_sequence(p) == 4) ? 1 : 0;
+  return SLQ_OK;
+}
+
+// Byte accounting of the store-and-revisit update sweep, which reads a ring column only when SOME probe of the panel projects on it (k_reorth_update): how many
+// columns it read and how many it was offered, summed over launches and panels since the last reset. Synchronises.
+extern "C" int slq_plan_sweep_columns(slq_plan *p, uint64_t *read, uint64_t *offered, int reset) {
+  if (!p) return fail(SLQ_EINVAL, "plan is NULL");
+  HIP_TRY(hipSetDevice(p->ctx->device));
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, p->sweep_cols_d, sizeof(h), hipMemcpyDeviceToHost, p->ctx->stream));
+  if (reset) HIP_TRY(hipMemsetAsync(p->sweep_cols_d, 0, sizeof(h), p->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  if (read) *read = h[0];
+  if (offered) *offered = h[1];
   return SLQ_OK;
 }
 
@@ -2896,7 +2916,7 @@ static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds,
     }
   }
   k_reorth_update<F, L><<<gS, dim3(kBlock), lds, st>>>(p->n, (F *)p->ring, p->slot_stride, p->S, j, i0, rc, p->st.gamma + (size_t)i0 * p->bpad,
-                                                     p->part, p->bpad, axpy ? p->st.coefB : nullptr);
+                                                     p->part, p->bpad, axpy ? p->st.coefB : nullptr, p->sweep_cols_d, p->sweep_skip ? 1 : 0);
 }
 
 // one fused CSR pass; the pipelined row loop exists for one-row-per-wave panels (L == 64) and not for the alpha pass
@@ -3443,7 +3463,7 @@ extern "C" int slq_plan_get_basis(slq_plan *p, int probe, void *Q, int64_t ldq) 
 
 static int update_chunk_cols(const slq_plan *p) {
   const int V = p->dtype == SLQ_F64 ? 2 : 4;
-  return (int)((150 * 1024 - sizeof(double) * kWaves * 64 * V) / ((size_t)p->PW * p->esz));
+  return std::min(192, (int)((150 * 1024 - sizeof(double) * kWaves * 64 * V) / ((size_t)p->PW * p->esz + sizeof(int))));  // (192: the update sweep's column masks)
 }
 
 // w(slot (j+1)%S) -= sum_{i<r} gamma[i] * W_{j-i}, gamma staged through LDS in chunks
@@ -3456,7 +3476,7 @@ static int launch_reorth_update_range(slq_plan *p, int j, int istart, int r, boo
   const dim3 gS(p->nblkS, p->NP);
   for (int i0 = istart; i0 < r; i0 += kUpdChunk) {
     const int rc = std::min(kUpdChunk, r - i0);
-    const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz;
+    const size_t lds = sizeof(double) * kWaves * 64 * V + (size_t)rc * p->PW * p->esz + (size_t)rc * sizeof(int);  // reduction scratch, gamma, per-column flags
     PROFILED(p, klass,
              DISPATCH(p->dtype, p->LPR,
                       (launch_reorth_update_kernel<F, L>(p, gS, lds, st, j, i0, rc, (int)(i0 + rc >= r), axpy && i0 == 0))));  // last chunk: w is final; (axpy: column 0 of the chunk must be W_c)

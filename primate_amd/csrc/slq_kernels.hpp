@@ -1718,20 +1718,41 @@ template <typename F, int LPR>
 __global__ __launch_bounds__(kBlock) void k_reorth_update(
     int n, F *ring, int64_t slot_stride, int S, int j, int i0, int r,
     const double *__restrict__ gamma /* [r][bpad], already offset to column i0 */,
-    double *__restrict__ partN, int bpad, const double *__restrict__ coefB /* non-null: w -= cB W_c first (k_reorth_dot mode 2) */) {
+    double *__restrict__ partN, int bpad, const double *__restrict__ coefB /* non-null: w -= cB W_c first (k_reorth_dot mode 2) */,
+    unsigned long long *__restrict__ cols_stat /* null, or {columns read, columns offered} summed over launches and panels (byte accounting) */,
+    int skip_zero_cols /* 0: every column is read (SLQ_SWEEP_SKIP=0: A/B and the bitwise check) */) {
   using VF = typename VecT<F>::type;
   constexpr int V = Geo<F, LPR>::V, PW = Geo<F, LPR>::PW, RPW = Geo<F, LPR>::RPW;
   constexpr int UR = SLQ_UPD_UR;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double *red = (double *)lds_raw;                       // kWaves*64*V doubles
   F *gl = (F *)(lds_raw + sizeof(double) * kWaves * 64 * V); // r * PW
+  int *fl = (int *)(gl + (size_t)r * PW);                    // r flags: column i has a non-zero coefficient for SOME probe of this panel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LPR, cl = lane % LPR;
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + cl * V;
-  for (int t = threadIdx.x; t < r * PW; t += kBlock)
-    gl[t] = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+  for (int t = threadIdx.x; t < r; t += kBlock) fl[t] = 0;
   __syncthreads();
+  for (int t = threadIdx.x; t < r * PW; t += kBlock) {
+    const F gv = (F)gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+    gl[t] = gv;
+    if (gv != (F)0) fl[t / PW] = 1;  // (every writer writes 1)
+  }
+  __syncthreads();
+  // Columns whose coefficient is zero for EVERY probe of the panel are not read at all (r04). The reference skips a projection per probe when it is below its
+  // threshold (lanczos.h:62) - in a well-conditioned run that is nearly every column of a deep window - and `w -= 0 * x` is w for finite x: bitwise the same result,
+  // minus the panel read. The flags as wave-uniform bit masks (r <= 192: update_chunk_cols).
+  unsigned long long live_cols[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) live_cols[q] = __builtin_amdgcn_ballot_w64(q * 64 + lane < r && fl[min(q * 64 + lane, r - 1)] != 0);
+  if (coefB) live_cols[0] |= 1ull;  // (column 0 carries the deferred three-term axpy)
+  if (!skip_zero_cols) live_cols[0] = live_cols[1] = live_cols[2] = ~0ull;
+  if (cols_stat && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int nlive = __builtin_popcountll(live_cols[0]) + __builtin_popcountll(live_cols[1]) + __builtin_popcountll(live_cols[2]);
+    atomicAdd(cols_stat, (unsigned long long)(skip_zero_cols ? nlive : r));
+    atomicAdd(cols_stat + 1, (unsigned long long)r);
+  }
   F *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   const F *U0 = ring + poff;
   VF cb = (VF)(F)0;
@@ -1753,6 +1774,7 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update(
       w[u] = stream_load<SLQ_SWEEP_LDW>((const VF *)(W + ro[u]));
     }
     for (int i = 0; i < r; ++i) {
+      if (!((live_cols[i >> 6] >> (i & 63)) & 1ull)) continue;
       const F *U = U0 + (int64_t)ring_slot(j - i0 - i, S) * slot_stride;
       const VF gm = *(const VF *)(gl + i * PW + cl * V);
       VF x[UR];

@@ -351,6 +351,13 @@ class LanczosPlan:
 		check(_capi.lib().slq_plan_profile_read(self._h, C.byref(pr), int(reset)))
 		return {k: {"ms": pr.ms[i], "launches": pr.launches[i]} for i, k in enumerate(_capi.KERNEL_CLASSES)}
 
+	def sweep_columns(self, reset: bool = True) -> tuple:
+		"""(read, offered): ring columns the deep-window update sweeps actually read against the ones their windows hold, summed over launches and panels - the
+		sweep skips a column whose projection is below the reference's threshold for every probe of the panel (slq_plan_sweep_columns)."""
+		a, b = C.c_uint64(), C.c_uint64()
+		check(_capi.lib().slq_plan_sweep_columns(self._h, C.byref(a), C.byref(b), int(reset)))
+		return int(a.value), int(b.value)
+
 	def close(self):
 		if getattr(self, "_h", None):
 			_capi.lib().slq_plan_destroy(self._h)

@@ -60,10 +60,11 @@ int main(int argc, char **argv) {
   const bool brief = argc > 1;  // any argument: the in-place sweeps at the production residency only (A/B of store flavours)
   const int n = 1000000, NP = 2, PW = 128, bpad = 256, S = 31;
   const size_t slot = (size_t)NP * n * PW;  // elements per ring slot (both panels)
-  double *ring, *sink, *coef, *part;
+  double *ring, *sink, *coef, *part, *gam;  // coef: zeros (cB); gam: non-zero projections (an all-zero column is not read at all since r04)
   CK(hipMalloc(&ring, S * slot * 8)); CK(hipMemset(ring, 0, S * slot * 8));
   CK(hipMalloc(&sink, 8)); CK(hipMalloc(&coef, 64 * bpad * 8)); CK(hipMemset(coef, 0, 64 * bpad * 8));
   CK(hipMalloc(&part, (size_t)17 * 2048 * bpad * 8));
+  CK(hipMalloc(&gam, 64 * bpad * 8)); CK(hipMemset(gam, 0x3f, 64 * bpad * 8));
   CK(hipFuncSetAttribute((const void *)k_reorth_update<double, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const double GB17 = 17.0 * n * 1024.0 / 1e9;
   for (int data = 0; data < (brief ? 1 : 2); ++data) {
@@ -93,17 +94,17 @@ int main(int argc, char **argv) {
       printf("D  k_reorth_dot    later chunk rc=16 (17 reads)  blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * GB17 / t * 1e3);
       t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 0, 16, 1, coef, part, bpad); }, 5);
       printf("D  k_reorth_dot    first chunk rc=16 (17R + 1W)  blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
-      const size_t lds = sizeof(double) * kWaves * 64 * 2 + (size_t)16 * PW * 8;
-      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, coef, part, bpad, nullptr); }, 5);
+      const size_t lds = sizeof(double) * kWaves * 64 * 2 + (size_t)16 * PW * 8 + 16 * 4;
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, gam, part, bpad, nullptr, nullptr, 1); }, 5);
       printf("E  k_reorth_update r=16 (17R + 1W)               blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
       t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 0, 16, 2, coef, part, bpad); }, 5);
       printf("D' k_reorth_dot    first chunk, axpy deferred (17R) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 17.0 * n * 1024 / 1e9 / t * 1e3);
       t = timeit([&] { k_reorth_dot<double, 64><<<dim3(blocks, 2), kBlock>>>(n, ring, (int64_t)slot, S, 40, 16, 14, 2, coef, part, bpad); }, 5);
       printf("D' k_reorth_dot    later chunk rc=14, deferred (16R) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 16.0 * n * 1024 / 1e9 / t * 1e3);
-      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, coef, part, bpad, coef); }, 5);
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds>>>(n, ring, (int64_t)slot, S, 40, 0, 16, gam, part, bpad, coef, nullptr, 1); }, 5);
       printf("E' k_reorth_update r=16 + deferred axpy (17R + 1W) blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 18.0 * n * 1024 / 1e9 / t * 1e3);
-      const size_t lds30 = sizeof(double) * kWaves * 64 * 2 + (size_t)30 * PW * 8;
-      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds30>>>(n, ring, (int64_t)slot, S, 40, 0, 30, coef, part, bpad, nullptr); }, 3);
+      const size_t lds30 = sizeof(double) * kWaves * 64 * 2 + (size_t)30 * PW * 8 + 30 * 4;
+      t = timeit([&] { k_reorth_update<double, 64><<<dim3(blocks, 2), kBlock, lds30>>>(n, ring, (int64_t)slot, S, 40, 0, 30, gam, part, bpad, nullptr, nullptr, 1); }, 3);
       printf("E  k_reorth_update r=30 (31R + 1W)               blocks=%4d x 2    %.3f ms  %.0f GB/s\n", blocks, t, 2 * 32.0 * n * 1024 / 1e9 / t * 1e3);
     }
   }

@@ -39,7 +39,7 @@ def lanczos_roofline(plan, A, b, deg, orth, batches):
 	n, nnz, s = A.shape[0], A.nnz, A.dtype.itemsize
 	## (every config here draws its probes on the device; Rademacher ones need no norm sweep since r04)
 	kb, kl = bench.kernel_bytes(n, nnz, s, b, info["panel_width"], deg, orth, sequence=info["sequence"], upper_alpha=bool(info["upper_alpha"]), norm_sweep=False,
-	                            last_nostore=not plan.keep_basis)
+	                            last_nostore=not plan.keep_basis, sweep_live_frac=(lambda rd, off: rd / off if off else 1.0)(*plan.sweep_columns(reset=True)))
 	prof = plan.profile_read(reset=True)
 	rows = {}
 	for k, v in prof.items():

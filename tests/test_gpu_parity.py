@@ -825,6 +825,49 @@ def test_pipelined_row_loop_with_empty_rows(oracle, eng, monkeypatch, dtype, rto
 	op.close()
 
 
+def test_update_sweep_skips_columns_nobody_projects_on(oracle, eng, monkeypatch):
+	"""Deep windows (orth > 8: the store-and-revisit sweeps). The reference skips a projection per probe when it is below 2 eps sqrt(n) (lanczos.h:53,62); the update
+	sweep does not even READ a ring column whose coefficient is zero for every probe of its panel (r04). `w -= 0 * x` is w, so the results are bitwise those of the
+	sweep that reads everything (SLQ_SWEEP_SKIP=0); on a well-conditioned grid nearly every column of a 20-column window is skipped, on the reference's ill-conditioned
+	full-reorth test matrix (tests/test_lanczos.py:11-20 shape: eigenvalues over seven decades) hardly any - and both follow the oracle."""
+	rng = np.random.default_rng(13)
+	A = laplacian_2d(90)
+	n = A.shape[0]
+	X = np.asfortranarray(np.floor(rng.random((n, 40)) * 2) * 2 - 1)
+	op = eng.DeviceOperator(A)
+	res = {}
+	for skip in ("1", "0"):
+		monkeypatch.setenv("SLQ_SWEEP_SKIP", skip)
+		plan = eng.LanczosPlan(op, 40, 24, 24)
+		plan.set_probes(X)
+		plan.run()
+		res[skip] = (plan.quadrature("log"), plan.tridiag(), plan.sweep_columns())
+		plan.close()
+	monkeypatch.delenv("SLQ_SWEEP_SKIP")
+	assert np.array_equal(res["1"][0], res["0"][0]) and all(np.array_equal(a, b) for a, b in zip(res["1"][1], res["0"][1]))
+	rd1, off1 = res["1"][2]
+	rd0, off0 = res["0"][2]
+	assert off1 == off0 > 0 and rd0 == off0 and rd1 < 0.5 * off1, (rd1, off1, rd0, off0)
+	np.testing.assert_allclose(res["1"][0][[0, 39]], oracle.quad_batch(A, np.asfortranarray(X[:, [0, 39]]), 24, 24, fun="log", fresh_q=True), rtol=1e-10)
+	op.close()
+	## an operator on which the window's projections are NOT small: dense SPD with eigenvalues over seven decades, full reorthogonalisation
+	m = 300
+	Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+	D = (Q * np.logspace(-3, 4, m)) @ Q.T
+	D = np.asfortranarray((D + D.T) / 2)
+	Xd = np.asfortranarray(rng.standard_normal((m, 20)))
+	opd = eng.DeviceOperator(D)
+	plan = eng.LanczosPlan(opd, 20, 40, 40)
+	plan.set_probes(Xd)
+	plan.run()
+	got = plan.quadrature("log")
+	rd, off = plan.sweep_columns()
+	plan.close()
+	opd.close()
+	assert rd > 0.5 * off, (rd, off)
+	np.testing.assert_allclose(got, oracle.quad_batch(D, Xd, 40, 40, fun="log", fresh_q=True), rtol=1e-8)
+
+
 def test_opt_in_fp32_archive_ring(oracle, eng, monkeypatch):
 	"""SLQ_RING32=1 (opt-in): finished Lanczos vectors archived as fp32, reorthogonalisation columns j-2 and older read
 	from the archive. Not bit-compatible by construction; the bar here is 1e-7 relative per probe against the oracle
