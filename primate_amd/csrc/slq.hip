@@ -25,6 +25,7 @@
 #include "slq_kernels.hpp"
 #include "slq_ring_api.h"
 #include "slq_ring.hpp"  // (RingGeo constants: no kernel of it is instantiated here)
+#include "slq_build.hpp"  // an operator's derived data built on the device
 
 using namespace slq;
 
@@ -114,6 +115,7 @@ struct slq_operator {
   int32_t *tile_desc_u = nullptr;  // the same over the upper triangle (exactly symmetric operators): the alpha-only pass
   char *tile_rec_u = nullptr;
   int32_t xcd_tile_u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // tile ranges of the upper-triangle stream, whose tiles are runs of the base tiles (regroup_upper_tiles, r04)
+  size_t tile_desc_bytes = 0, tile_rec_bytes = 0, tile_desc_u_bytes = 0, tile_rec_u_bytes = 0;  // (what SLQ_DEVICE_BUILD=2 compares)
   int tile_max_lines_u = 0;        // longest line list of a tile in that stream (short lists: a ring geometry with one slot more)
   bool tile_u_padded = false;      // ... with every row's entries padded to a multiple of four (build_ring_stream: pad_rows)
   double upper_per_row = 0.0;      // distinct panel rows per row that stream lands (what decides whether the alpha-only pass takes it)
@@ -476,8 +478,10 @@ static int check_dtype(int dtype) {
 // the reuse-distance model above (fewer resident workgroups also fetch MORE, not less).
 // sub: second-level pieces per chunk (below). avg_level: if not null, receives the mean size of the breadth-first level sets of
 // the final order - what a tile sweep has to keep in L2 between a row and its neighbours in the next level.
+// first_level: the order a call with sub = 1 returned for this matrix (null: computed here) - the sweep over sub = 4, 16, 64 of
+// csr_create_body does the chunks' own Cuthill-McKee once (r04: it was redone per attempt, 12 ms of a 100^3 operator's creation).
 static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t *colind, std::vector<int32_t> &perm, int sub,
-                                double *avg_level) {
+                                double *avg_level, const std::vector<int32_t> *first_level = nullptr) {
   perm.resize((size_t)n);
   const int64_t chunk = (n + 7) / 8;
   // The eight chunks are independent: one worker each. deg / part / seen are indexed by node and a worker touches the
@@ -549,12 +553,16 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
       for (int32_t v : mem) seen[(size_t)v] = 0;
       out.insert(out.end(), order.rbegin(), order.rend());  // reversed (RCM)
     };
-    members.resize((size_t)(hi - lo));
-    for (int64_t i = lo; i < hi; ++i) {
-      members[(size_t)(i - lo)] = (int32_t)i;
-      part[(size_t)i] = x;
+    if (first_level && sub > 1) {
+      first.assign(first_level->begin() + lo, first_level->begin() + hi);
+    } else {
+      members.resize((size_t)(hi - lo));
+      for (int64_t i = lo; i < hi; ++i) {
+        members[(size_t)(i - lo)] = (int32_t)i;
+        part[(size_t)i] = x;
+      }
+      rcm(members, x, first);
     }
-    rcm(members, x, first);
     // Second level (SLQ_RCM_SUB = K > 1): the chunk's RCM order is cut into K consecutive pieces of equal size - runs of
     // BFS levels, i.e. slices ACROSS the chunk's longest direction - and each piece is reordered on its own. A piece is
     // short along the old sweep direction, so its own Cuthill-McKee levels run along another one and are K times
@@ -593,8 +601,9 @@ static void xcd_rcm_permutation(int64_t n, const int32_t *rowptr, const int32_t 
 // so the sweep of the chunk keeps its locality. order_in: stored row -> caller row; inv_in: caller row -> stored row
 // (null: identity). order_out: the new stored order; tile_row: first stored row of every tile; xcd_tile: tile range of
 // every chunk. Returns false when a single row already needs more than kTileCols indices (no tiling for this operator).
+// *lines_total (if not null): the sum over the clusters of their distinct indices (rows and columns) - the panel rows a sweep of the tiles lands.
 static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *colind, const int32_t *order_in, const int32_t *inv_in,
-                           std::vector<int32_t> &order_out, std::vector<int32_t> &tile_row, int32_t xcd_tile[9]) {
+                           std::vector<int32_t> &order_out, std::vector<int32_t> &tile_row, int32_t xcd_tile[9], int64_t *lines_total = nullptr) {
   const int64_t chunk = (n + 7) / 8;
   const bool ringed = tiles_mode() == 2;  // tiles of the ring-fed kernel (k_csr_ring_pass): smaller, fixed caps
   const int tmax = ringed ? kRingTileRows : std::max(1, std::min(env_int("SLQ_TILE_ROWS", kTileRows), 64));
@@ -609,6 +618,7 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
   constexpr int kClusterPieces = 2, NX = 8 * kClusterPieces;
   std::vector<char> assigned((size_t)n, 0);
   std::vector<int32_t> order_x[NX], rows_x[NX];  // per piece: the new order, and the row count of every cluster
+  int64_t lines_x[NX] = {};
   char failed[NX] = {};
   auto do_chunk = [&](int x) {
     const int64_t clo = (x / kClusterPieces) * chunk, chi = std::min<int64_t>(n, clo + chunk);
@@ -619,6 +629,9 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
     std::vector<int32_t> stamp((size_t)n, -1);
     struct Cand { int32_t node, cnt, disc; };
     std::vector<Cand> cand;
+    // where a node of this piece sits in `cand` while it is a candidate of the current cluster (r04: the list was searched linearly for every
+    // neighbour of every added row - 20 of the 35 ms this took on a 100^3 grid); indexed by position in the piece
+    std::vector<int32_t> slot_of((size_t)(hi - lo), -1);
     std::vector<int32_t> &order = order_x[x];
     order.reserve((size_t)(hi - lo));
     int32_t cid = 0;
@@ -646,9 +659,9 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
           const int32_t c = colind[p];
           if (stamp[(size_t)c] != cid) { stamp[(size_t)c] = cid; ++D; }
           if (c != v && in_chunk(c) && !assigned[(size_t)c]) {
-            bool found = false;
-            for (auto &k : cand) if (k.node == c) { ++k.cnt; found = true; break; }
-            if (!found) cand.push_back(Cand{c, 1, ndisc++});
+            int32_t &slot = slot_of[(size_t)((inv_in ? inv_in[c] : c) - lo)];
+            if (slot >= 0) ++cand[(size_t)slot].cnt;
+            else slot = (int32_t)cand.size(), cand.push_back(Cand{c, 1, ndisc++});
           }
         }
       };
@@ -659,12 +672,16 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
         for (size_t q = 1; q < cand.size(); ++q)
           if (cand[q].cnt > cand[best].cnt || (cand[q].cnt == cand[best].cnt && cand[q].disc < cand[best].disc)) best = q;
         const int32_t v = cand[best].node;
+        slot_of[(size_t)((inv_in ? inv_in[v] : v) - lo)] = -1;
         cand[best] = cand.back();
         cand.pop_back();
+        if (best < cand.size()) slot_of[(size_t)((inv_in ? inv_in[cand[best].node] : cand[best].node) - lo)] = (int32_t)best;
         if (assigned[(size_t)v]) continue;
         if (D + new_cols(v) > dcap || nz + rowptr[v + 1] - rowptr[v] > nzcap) continue;  // would not fit: leave it for a later cluster
         add(v);
       }
+      for (const Cand &k : cand) slot_of[(size_t)((inv_in ? inv_in[k.node] : k.node) - lo)] = -1;  // (what the cluster leaves behind)
+      lines_x[x] += D;
       rows_x[x].push_back((int32_t)(order.size() - first_member));
       ++cid;
     }
@@ -685,6 +702,10 @@ static bool build_clusters(int64_t n, const int32_t *rowptr, const int32_t *coli
   }
   xcd_tile[8] = (int32_t)tile_row.size() - 1;
   for (int x = 7; x >= 0; --x) xcd_tile[x] = std::min(xcd_tile[x], xcd_tile[x + 1]);
+  if (lines_total) {
+    *lines_total = 0;
+    for (int x = 0; x < NX; ++x) *lines_total += lines_x[x];
+  }
   return (int64_t)order_out.size() == n;
 }
 
@@ -900,44 +921,50 @@ static void build_ring_stream(int R, const int32_t *rowptr, const F *vals, const
 // halo - are joined while the run keeps to kRingTileRows rows, kRingTileCols distinct lines (rows and upper columns) and kRingTileNnz padded entries: 100^3, 118,940 ->
 // 107,848 tiles, alpha pass 0.652 -> 0.607 ms. (Cutting the chunk's rows anew, row by row, to the same caps gives 12.9-row tiles that straddle cluster boundaries and
 // land MORE lines per row, 2.65 against 2.47: 0.82 ms. Not kept.) Tiles stay contiguous row ranges of one XCD chunk; kernel and stream format do not change.
-static void regroup_upper_tiles(const int32_t *urp, const int32_t *uci, const std::vector<int32_t> &tile_row, const int32_t xcd_tile[9],
-                                std::vector<int32_t> &tile_row_u, int32_t xcd_tile_u[9]) {
+// each_upper(r, consider): calls consider(c) for every column c >= r of stored row r and returns how many there were (the upper
+// triangle's CSR, or - before that exists - the caller's CSR seen through the permutation: the columns' order does not matter)
+template <typename EachUpper>
+static void regroup_upper_tiles_impl(EachUpper each_upper, const std::vector<int32_t> &tile_row, const int32_t xcd_tile[9],
+                                     std::vector<int32_t> &tile_row_u, int32_t xcd_tile_u[9]) {
   auto padded = [](int32_t cnt) { return std::max<int32_t>(4, (cnt + 3) / 4 * 4); };
   // every chunk on its own (in parallel): consecutive base tiles - neighbours in the sweep - joined while the run keeps to the caps
   std::vector<int32_t> cuts[8];
   const bool ok = parallel_pieces(8, 8, [&](int, int64_t x0, int64_t x1) {
     for (int64_t x = x0; x < x1; ++x) {
       std::vector<int32_t> &out = cuts[x];
-      int32_t lines[2 * kRingTileCols + 16];
+      if (xcd_tile[x] >= xcd_tile[x + 1]) continue;
+      // membership by stamps (r04: the lists were searched linearly - 25 ms of a 100^3 operator's creation): in_run[c - base] == run: c is a line of
+      // the current run; in_tile[c - base] == stamp: c was counted for the base tile under consideration. Every column of a chunk's rows is >= base.
+      const int32_t base = tile_row[(size_t)xcd_tile[x]], n_all = tile_row.back();
+      std::vector<int32_t> in_run((size_t)(n_all - base), -1), in_tile((size_t)(n_all - base), -1);
+      int32_t run = 0, stamp = 0;
       int nl = 0, rows = 0, nz = 0;
       for (int32_t t = xcd_tile[x]; t < xcd_tile[x + 1]; ++t) {
         const int32_t r0 = tile_row[(size_t)t], r1 = tile_row[(size_t)t + 1];
-        // what this base tile would add to the run: its rows and their upper columns, unless already listed
-        int32_t fresh[kRingTileCols + 16];
-        int nf = 0;
+        // what this base tile lists - its rows and their upper columns, each once - and how much of that the run does not list yet
+        int32_t all[kRingTileCols + 16];
+        int na = 0, nf = 0;
         int32_t pz = 0;
         auto consider = [&](int32_t c) {
-          for (int q = 0; q < nl; ++q)
-            if (lines[q] == c) return;
-          for (int q = 0; q < nf; ++q)
-            if (fresh[q] == c) return;
-          if (nf < kRingTileCols + 16) fresh[nf++] = c;
+          const size_t k = (size_t)(c - base);
+          if (in_tile[k] == stamp) return;
+          in_tile[k] = stamp;
+          if (na < kRingTileCols + 16) all[na++] = c, nf += in_run[k] != run;
         };
         for (int32_t r = r0; r < r1; ++r) {
           consider(r);
-          for (int32_t q = urp[r]; q < urp[r + 1]; ++q) consider(uci[q]);
-          pz += padded(urp[r + 1] - urp[r]);
+          pz += padded(each_upper(r, consider));
         }
+        ++stamp;
         if (rows > 0 && (rows + (r1 - r0) > kRingTileRows || nl + nf > kRingTileCols || nz + pz > kRingTileNnz)) {
           nl = rows = nz = 0;  // cut: this base tile opens the next run (its own lines: everything it lists)
-          nf = 0;
-          for (int32_t r = r0; r < r1; ++r) {
-            consider(r);
-            for (int32_t q = urp[r]; q < urp[r + 1]; ++q) consider(uci[q]);
-          }
+          ++run;
         }
         if (rows == 0) out.push_back(r0);
-        for (int q = 0; q < nf && nl < 2 * kRingTileCols + 16; ++q) lines[nl++] = fresh[q];
+        for (int q = 0; q < na && nl < 2 * kRingTileCols + 16; ++q) {
+          int32_t &m = in_run[(size_t)(all[q] - base)];
+          if (m != run) m = run, ++nl;
+        }
         rows += r1 - r0;
         nz += pz;
       }
@@ -951,6 +978,15 @@ static void regroup_upper_tiles(const int32_t *urp, const int32_t *uci, const st
   }
   xcd_tile_u[8] = (int32_t)tile_row_u.size();
   tile_row_u.push_back(tile_row.back());
+}
+static void regroup_upper_tiles(const int32_t *urp, const int32_t *uci, const std::vector<int32_t> &tile_row, const int32_t xcd_tile[9],
+                                std::vector<int32_t> &tile_row_u, int32_t xcd_tile_u[9]) {
+  regroup_upper_tiles_impl(
+      [&](int32_t r, auto &consider) {
+        for (int32_t q = urp[r]; q < urp[r + 1]; ++q) consider(uci[q]);
+        return urp[r + 1] - urp[r];
+      },
+      tile_row, xcd_tile, tile_row_u, xcd_tile_u);
 }
 
 // If the CSR (rows sorted, no duplicates) is exactly symmetric, emit its upper triangle with the strict
@@ -999,10 +1035,135 @@ static bool build_symmetric_upper(int64_t n, const int32_t *rowptr, const int32_
   });
 }
 
+// ---- derived data built on the device (slq_build.hpp) ----
+struct DevBuf {  // device scratch of a build, freed when the build is left
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+  }
+  hipError_t alloc(size_t bytes) {
+    release();
+    return hipMalloc(&p, std::max<size_t>(bytes, 16));
+  }
+  template <typename T> T *as() const { return (T *)p; }
+  void *take() {
+    void *q = p;
+    p = nullptr;
+    return q;
+  }
+};
+// a[0, count) := its inclusive scan (the callers keep a zero in front of it: row pointers, record offsets)
+static hipError_t device_scan_inclusive(int32_t *a, int64_t count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  const int nb = (int)((count + slqb::kScanTile - 1) / slqb::kScanTile);
+  DevBuf sums;
+  hipError_t e = sums.alloc((size_t)nb * 4);
+  if (e != hipSuccess) return e;
+  slqb::k_scan_block_sums<<<dim3(nb), dim3(256), 0, st>>>(a, count, sums.as<int32_t>());
+  slqb::k_scan_sums<<<dim3(1), dim3(1024), 0, st>>>(sums.as<int32_t>(), nb);
+  slqb::k_scan_apply<<<dim3(nb), dim3(256), 0, st>>>(a, count, sums.as<int32_t>());
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // (sums is freed on return)
+  return e;
+}
+struct DeviceStream {  // what device_build_stream hands back (the caller owns desc, rec, tile_ptr)
+  int32_t *desc = nullptr;
+  char *rec = nullptr;
+  int32_t *tile_ptr = nullptr;  // [ntiles + 1] running sum of the lists' lengths (only if asked for)
+  size_t desc_bytes = 0, rec_bytes = 0;
+  int max_lines = 0;
+  int64_t sum_lines = 0;
+  bool padded = false;
+};
+// The descriptor / record stream of R-merged tiles `tile_row_d` (device, ntiles + 1) over the CSR (rp, ci, va) (device): what
+// build_tile_meta + build_ring_stream produce on the host, byte for byte. want_pad: rows padded to whole chunks of four entries
+// unless some record would outgrow its slot (out.padded tells). max_lines_per_row > 0: nothing is built (return 1) when the tiles
+// land more distinct panel rows per row than that; out.max_lines / out.sum_lines are set either way. 0: built; < 0: failed
+// (the SLQ status).
+static int device_build_stream(slq_context *ctx, int dtype, int R, int64_t n, const int32_t *rp, const int32_t *ci, const void *va, const int32_t *tile_row_d,
+                               int ntiles, bool want_pad, double max_lines_per_row, bool keep_tile_ptr, DeviceStream &out) {
+  hipStream_t st = ctx->stream;
+  const int cap = kRingTileCols * R;
+  const int es = (int)esize(dtype);
+  const int head_bytes = kRecHeadBytes * R, pad_limit = (kRingRecStride * R + 1023) / 1024 * 1024;
+  DevBuf lists, small;
+  const size_t cnt = (size_t)ntiles + 1;
+  hipError_t e = lists.alloc((size_t)ntiles * cap * 4);
+  if (e == hipSuccess) e = small.alloc((3 * cnt + 4) * 4);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile stream scratch: %s", hipGetErrorString(e));
+  int32_t *D = small.as<int32_t>(), *units = D + cnt, *units_pad = units + cnt;
+  int *flags = (int *)(units_pad + cnt);
+  e = hipMemsetAsync(small.p, 0, (3 * cnt + 4) * 4, st);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "tile stream scratch: %s", hipGetErrorString(e));
+  const dim3 gl((unsigned)((ntiles + 63) / 64));
+  if (R == 1) slqb::k_tile_lists<kRingTileCols><<<gl, dim3(64), 0, st>>>(ntiles, rp, ci, tile_row_d, lists.as<int32_t>(), D, units, units_pad, head_bytes, es, pad_limit, flags);
+  else if (R == 2) slqb::k_tile_lists<2 * kRingTileCols><<<gl, dim3(64), 0, st>>>(ntiles, rp, ci, tile_row_d, lists.as<int32_t>(), D, units, units_pad, head_bytes, es, pad_limit, flags);
+  else if (R == 4) slqb::k_tile_lists<4 * kRingTileCols><<<gl, dim3(64), 0, st>>>(ntiles, rp, ci, tile_row_d, lists.as<int32_t>(), D, units, units_pad, head_bytes, es, pad_limit, flags);
+  else return fail(SLQ_EINVAL, "tiles are merged 1, 2 or 4 at a time");
+  int hflags[4] = {0, 0, 0, 0};
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "tile lists: %s", hipGetErrorString(e));
+  if (hflags[0]) return fail(SLQ_EHIP, "a tile lists more than %d distinct panel rows (tiles not built to the ring's caps)", cap);
+  out.max_lines = hflags[2];
+  out.padded = want_pad && !hflags[1];
+  int32_t *u = out.padded ? units_pad : units;
+  e = device_scan_inclusive(D + 1, ntiles, st);
+  if (e == hipSuccess) e = device_scan_inclusive(u + 1, ntiles, st);
+  int32_t totals[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(&totals[0], D + ntiles, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(&totals[1], u + ntiles, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return fail(SLQ_EHIP, "tile stream offsets: %s", hipGetErrorString(e));
+  out.sum_lines = totals[0];
+  if (max_lines_per_row > 0.0 && (double)totals[0] / (double)n > max_lines_per_row) return 1;
+  DevBuf desc, rec, tptr;
+  out.desc_bytes = (size_t)ntiles * 64 * R * 4;
+  out.rec_bytes = (size_t)totals[1] * 16 + (size_t)kRingMetaBytes * R;
+  e = desc.alloc(out.desc_bytes);
+  if (e == hipSuccess) e = rec.alloc(out.rec_bytes);
+  if (e == hipSuccess && keep_tile_ptr) e = tptr.alloc(cnt * 4);
+  if (e == hipSuccess && keep_tile_ptr) e = hipMemcpyAsync(tptr.p, D, cnt * 4, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(rec.as<char>() + (size_t)totals[1] * 16, 0, (size_t)kRingMetaBytes * R, st);  // the spare record behind the last one
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "tile stream: %s", hipGetErrorString(e));
+  const dim3 gs((unsigned)((ntiles + 3) / 4));
+  const int pad = out.padded ? 1 : 0;
+#define SLQ_STREAM_LAUNCH(F, CAP) \
+  slqb::k_tile_stream<F, CAP><<<gs, dim3(256), 0, st>>>(ntiles, R, pad, rp, ci, (const F *)va, tile_row_d, lists.as<int32_t>(), D, u, desc.as<int32_t>(), rec.as<char>())
+  if (dtype == SLQ_F64) {
+    if (R == 1) SLQ_STREAM_LAUNCH(double, kRingTileCols);
+    else if (R == 2) SLQ_STREAM_LAUNCH(double, 2 * kRingTileCols);
+    else SLQ_STREAM_LAUNCH(double, 4 * kRingTileCols);
+  } else {
+    if (R == 1) SLQ_STREAM_LAUNCH(float, kRingTileCols);
+    else if (R == 2) SLQ_STREAM_LAUNCH(float, 2 * kRingTileCols);
+    else SLQ_STREAM_LAUNCH(float, 4 * kRingTileCols);
+  }
+#undef SLQ_STREAM_LAUNCH
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the scratch goes when this returns)
+  if (e != hipSuccess) return fail(SLQ_EHIP, "tile stream: %s", hipGetErrorString(e));
+  out.desc = (int32_t *)desc.take();
+  out.rec = (char *)rec.take();
+  out.tile_ptr = keep_tile_ptr ? (int32_t *)tptr.take() : nullptr;
+  return 0;
+}
+static bool device_equals_host(const void *dev, const void *host, size_t bytes) {
+  std::vector<char> tmp(bytes);
+  if (hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  return memcmp(tmp.data(), host, bytes) == 0;
+}
+
 // plain != 0: rows stay in the caller's order and no derived copy (upper triangle, tiles) is built - for operators whose
 // values change after creation (the affine operator)
 static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain);
+                           const void *vals, slq_operator **out, int plain, int host_build = 0);
 
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
@@ -1011,11 +1172,11 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
 }
 
 static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain);
+                           const void *vals, slq_operator **out, int plain, int host_build);
 static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain) {
+                           const void *vals, slq_operator **out, int plain, int host_build) {
   try {  // (host-side allocations of the analysis: no C++ exception crosses the C boundary)
-    return csr_create_body(ctx, dtype, n, nnz, rowptr, colind, vals, out, plain);
+    return csr_create_body(ctx, dtype, n, nnz, rowptr, colind, vals, out, plain, host_build);
   } catch (const std::bad_alloc &) {
     if (out) *out = nullptr;
     return fail(SLQ_ENOMEM, "host allocation failed while analysing the operator");
@@ -1025,8 +1186,12 @@ static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   }
 }
 
+static int csr_finish_on_device(slq_context *ctx, slq_operator *op, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr0, const int32_t *colind0,
+                                const int32_t *o_rp, const int32_t *o_ci, const void *o_va, UploadQueue &early, const std::vector<int32_t> &tile_row,
+                                const int32_t xcd_tile[9], PhaseClock &clk);
+static int operators_differ(const slq_operator *a, const slq_operator *b);
 static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain) {
+                           const void *vals, slq_operator **out, int plain, int host_build) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
   *out = nullptr;
   SLQ_TRY(check_dtype(dtype));
@@ -1125,6 +1290,21 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     if (q > 1.25 * kTileMaxColsPerRow) try_tiles = false;
   }
   clk.lap("tile sample");
+  // SLQ_DEVICE_BUILD (r04, slq_build.hpp): 1 (default) - an operator that gets ring-sized tiles has its stored CSR, upper triangle and
+  // tile streams built on the device from the caller's CSR, which starts its way up now, while the host orders and clusters the rows;
+  // 0 - everything on the host, as before; 2 - both, compared array by array (tests)
+  const int dev_mode = (plain || host_build) ? 0 : env_int("SLQ_DEVICE_BUILD", 1);
+  DevBuf o_rp, o_ci, o_va;       // the caller's CSR on the device (scratch of the build)
+  UploadQueue early(ctx->device);  // (declared after what it fills: joined first)
+  bool early_started = false;
+  if (dev_mode != 0 && try_tiles && tmode == 2 && reorder_mode != 0 && env_int("SLQ_RING_ORDER", 0) == 0) {
+    hipError_t ee = o_rp.alloc((size_t)(n + 1) * 4);
+    if (ee == hipSuccess) ee = o_ci.alloc((size_t)nnz * 4);
+    if (ee == hipSuccess) ee = o_va.alloc((size_t)nnz * esize(dtype));
+    if (ee != hipSuccess) return fail(ee == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(ee));
+    early.push({{o_rp.p, rowptr, (size_t)(n + 1) * 4}, {o_ci.p, colind, (size_t)nnz * 4}, {o_va.p, vals, (size_t)nnz * esize(dtype)}});
+    early_started = true;
+  }
   const double tile_limit = kTileMaxColsPerRow;
   std::vector<int32_t> tile_row;
   int32_t xcd_tile[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1136,29 +1316,9 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       inv0.resize((size_t)n);
       for (int64_t i = 0; i < n; ++i) inv0[(size_t)(*base)[(size_t)i]] = (int32_t)i;
     }
-    if (!build_clusters(n, rowptr, colind, base ? base->data() : nullptr, base ? inv0.data() : nullptr, order, tile_row, xcd_tile)) return false;
+    int64_t dsum = 0;  // distinct indices (rows and columns) summed over the tiles: the clusters count them as they grow
+    if (!build_clusters(n, rowptr, colind, base ? base->data() : nullptr, base ? inv0.data() : nullptr, order, tile_row, xcd_tile, &dsum)) return false;
     clk.lap("  clusters");
-    // distinct indices per tile row, on the caller's numbering (the exact lists are built below); tile ranges in parallel
-    const int pieces = host_threads();
-    std::vector<int64_t> dpart((size_t)pieces, 0);
-    if (!parallel_pieces(pieces, (int64_t)tile_row.size() - 1, [&](int piece, int64_t t0, int64_t t1) {
-      std::vector<int32_t> u;
-      int64_t d = 0;
-      for (int64_t t = t0; t < t1; ++t) {
-        u.clear();
-        for (int32_t q = tile_row[(size_t)t]; q < tile_row[(size_t)t + 1]; ++q) {
-          const int32_t v = order[(size_t)q];
-          u.push_back(v);
-          for (int32_t pp = rowptr[v]; pp < rowptr[v + 1]; ++pp) u.push_back(colind[pp]);
-        }
-        std::sort(u.begin(), u.end());
-        d += (int64_t)(std::unique(u.begin(), u.end()) - u.begin());
-      }
-      dpart[(size_t)piece] = d;
-    })) throw std::bad_alloc();  // (an undercounted sum would bias the decision whether the tiles are kept)
-    int64_t dsum = 0;
-    for (int64_t d : dpart) dsum += d;
-    clk.lap("  lines per row");
     const double per_row = (double)dsum / (double)n;
     if (env_int("SLQ_DEBUG", 0) != 0)
       fprintf(stderr, "[slq] tiles: %zu clusters, %.2f rows each, %.2f distinct panel rows per row (limit %.1f)\n", tile_row.size() - 1,
@@ -1189,8 +1349,10 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (try_tiles && tmode == 2 && reorder_mode != 0) {
     if (sub_env <= 0) {
       double w = 0.0;
+      std::vector<int32_t> level1;  // the chunks' own order (k = 1), which every finer attempt starts from
       for (int k = 1; k <= 64; k *= 4) {
-        xcd_rcm_permutation(n, rowptr, colind, rcm_perm, k, &w);
+        if (k == 4) level1 = rcm_perm;
+        xcd_rcm_permutation(n, rowptr, colind, rcm_perm, k, &w, k > 1 ? &level1 : nullptr);
         clk.lap("  Cuthill-McKee in the chunks");
         if (env_int("SLQ_DEBUG", 0) != 0) fprintf(stderr, "[slq] tiles: %d piece(s) per chunk: level sets of %.0f rows on average\n", k, w);
         if (w <= kTileLevelRows) break;
@@ -1241,6 +1403,26 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   }
   if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
   clk.lap("reorder decision");
+  if (early_started && have_tiles && op->perm_h) {
+    const int rc = csr_finish_on_device(ctx, op, dtype, n, nnz, rowptr, colind, o_rp.as<int32_t>(), o_ci.as<int32_t>(), o_va.p, early, tile_row, xcd_tile, clk);
+    if (rc != SLQ_OK) return rc;
+    if (dev_mode == 2) {  // the same operator built on the host: every array must be the same
+      slq_operator *ref = nullptr;
+      const int rr = csr_create_impl(ctx, dtype, n, nnz, rowptr, colind, vals, &ref, plain, 1);
+      if (rr != SLQ_OK) return rr;
+      const int diff = operators_differ(op, ref);
+      slq_operator_destroy(ref);
+      if (diff) return fail(SLQ_EHIP, "SLQ_DEVICE_BUILD=2: the device-built operator differs from the host-built one (item %d)", diff);
+    }
+    clk.total("all of slq_csr_create");
+    guard.op = nullptr;
+    *out = op;
+    return SLQ_OK;
+  }
+  if (early_started) {  // no tiles after all: the host path below uploads what it builds
+    early.wait();
+    o_rp.release(), o_ci.release(), o_va.release();
+  }
   // From here on every array goes to the device through `up` while the next one is being built; the buffers it reads are
   // declared before it and nothing returns without up.wait() (its destructor, at the latest).
   std::vector<int32_t> inv_keep;                  // stored row of every caller row (reordered operators)
@@ -1380,6 +1562,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
       clk.lap("  tile stream");
       te = hipMalloc((void **)&op->tile_desc, desc.size() * 4);
       if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec, rec.size());
+      op->tile_desc_bytes = desc.size() * 4, op->tile_rec_bytes = rec.size();
       if (te == hipSuccess) up.push({{op->tile_desc, desc.data(), desc.size() * 4}, {op->tile_rec, rec.data(), rec.size()}});
       if (te == hipSuccess && sym) {
         // the same tiles over the upper triangle (doubled off-diagonals), for the alpha-only pass: a tile's image then holds its
@@ -1418,6 +1601,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
           clk.lap("  upper tile stream");
           te = hipMalloc((void **)&op->tile_desc_u, desc_u.size() * 4);
           if (te == hipSuccess) te = hipMalloc((void **)&op->tile_rec_u, rec_u.size());
+          op->tile_desc_u_bytes = desc_u.size() * 4, op->tile_rec_u_bytes = rec_u.size();
           if (te == hipSuccess) up.push({{op->tile_desc_u, desc_u.data(), desc_u.size() * 4}, {op->tile_rec_u, rec_u.data(), rec_u.size()}});
         }
       }
@@ -1432,6 +1616,211 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   guard.op = nullptr;
   *out = op;
   return SLQ_OK;
+}
+
+// The second half of slq_csr_create for operators with ring-sized tiles (SLQ_DEVICE_BUILD, slq_build.hpp): given the order and the
+// tiles (host), everything stored with the operator is built on the device from the caller's CSR (o_rp, o_ci, o_va: on their way up
+// through `early`): the permuted CSR, the far-gather count, the symmetry check and the upper triangle, both tile streams. The one
+// sequential piece left - the runs of base tiles the upper-triangle stream's tiles are made of (regroup_upper_tiles) - runs on a host
+// thread meanwhile, on the caller's CSR seen through the permutation.
+static int csr_finish_on_device(slq_context *ctx, slq_operator *op, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr0, const int32_t *colind0,
+                                const int32_t *o_rp, const int32_t *o_ci, const void *o_va, UploadQueue &early, const std::vector<int32_t> &tile_row,
+                                const int32_t xcd_tile[9], PhaseClock &clk) {
+  hipStream_t st = ctx->stream;
+  const size_t es = esize(dtype);
+  const std::vector<int32_t> &perm = *op->perm_h;
+  const int ntiles = (int)tile_row.size() - 1;
+  std::vector<int32_t> inv((size_t)n), rp2((size_t)n + 1);
+  for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+  rp2[0] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t o = perm[(size_t)i];
+    rp2[(size_t)i + 1] = rp2[(size_t)i] + (rowptr0[o + 1] - rowptr0[o]);
+  }
+  const bool want_sym = env_int("SLQ_SYM_ALPHA", 1) != 0;
+  const bool tall_already = (double)n / (double)ntiles > 0.8 * kRingTileRows;
+  const bool regroup = want_sym && env_int("SLQ_RING_UPPER_REGROUP", 1) != 0 && !tall_already;
+  std::vector<int32_t> tile_row_u;
+  int32_t xcd_u[9];
+  for (int x = 0; x < 9; ++x) xcd_u[x] = xcd_tile[x];
+  std::atomic<int> rg_failed{0};
+  auto do_regroup = [&]() {
+    try {
+      regroup_upper_tiles_impl(
+          [&](int32_t r, auto &consider) {
+            const int32_t o = perm[(size_t)r];
+            int32_t cnt = 0;
+            for (int32_t q = rowptr0[o]; q < rowptr0[o + 1]; ++q) {
+              const int32_t c = inv[(size_t)colind0[q]];
+              if (c >= r) consider(c), ++cnt;
+            }
+            return cnt;
+          },
+          tile_row, xcd_tile, tile_row_u, xcd_u);
+    } catch (...) {
+      rg_failed = 1;
+    }
+  };
+  std::thread rg;
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{rg};
+  if (regroup) {
+    try {
+      rg = std::thread(do_regroup);
+    } catch (const std::system_error &) {
+      do_regroup();
+    }
+  }
+  auto hip_fail = [&](const char *what, hipError_t e) { return fail(e == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "%s: %s", what, hipGetErrorString(e)); };
+  int32_t *d_tr = nullptr;
+  hipError_t e = hipMalloc((void **)&op->perm_d, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->inv_perm_d, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->rowptr, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&op->colind, ((size_t)nnz + kCsrPad) * 4);
+  if (e == hipSuccess) e = hipMalloc(&op->vals, ((size_t)nnz + kCsrPad) * es);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_tr, tile_row.size() * 4);
+  op->tiles.tile_row = d_tr;
+  if (e == hipSuccess) e = hipMemcpy(op->perm_d, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(op->inv_perm_d, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(op->rowptr, rp2.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_tr, tile_row.data(), tile_row.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(op->colind + nnz, 0, kCsrPad * 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals + (size_t)nnz * es, 0, kCsrPad * es, st);
+  if (e == hipSuccess) e = early.wait();
+  if (e != hipSuccess) return hip_fail("CSR upload", e);
+  clk.lap("  order, tile boundaries and the caller's CSR on the device");
+  const dim3 grow((unsigned)((n + 255) / 256)), brow(256);
+  if (dtype == SLQ_F64) slqb::k_permute_csr<double><<<grow, brow, 0, st>>>((int)n, o_rp, o_ci, (const double *)o_va, op->perm_d, op->inv_perm_d, op->rowptr, op->colind, (double *)op->vals);
+  else slqb::k_permute_csr<float><<<grow, brow, 0, st>>>((int)n, o_rp, o_ci, (const float *)o_va, op->perm_d, op->inv_perm_d, op->rowptr, op->colind, (float *)op->vals);
+  DevBuf misc;  // [0..1] far gathers (u64), [2] "not symmetric"
+  e = misc.alloc(16);
+  if (e == hipSuccess) e = hipMemsetAsync(misc.p, 0, 16, st);
+  if (e != hipSuccess) return hip_fail("operator analysis", e);
+  slqb::k_far_count<<<grow, brow, 0, st>>>((int)n, op->rowptr, op->colind, misc.as<unsigned long long>());
+  if (want_sym) {
+    e = hipMalloc((void **)&op->rowptr_u, (size_t)(n + 1) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(op->rowptr_u, 0, 4, st);
+    if (e != hipSuccess) return hip_fail("upper triangle", e);
+    if (dtype == SLQ_F64) slqb::k_sym_count<double><<<grow, brow, 0, st>>>((int)n, op->rowptr, op->colind, (const double *)op->vals, op->rowptr_u, misc.as<int>() + 2);
+    else slqb::k_sym_count<float><<<grow, brow, 0, st>>>((int)n, op->rowptr, op->colind, (const float *)op->vals, op->rowptr_u, misc.as<int>() + 2);
+  }
+  struct { unsigned long long far; int bad, spare; } h = {0, 0, 0};
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, misc.p, 16, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail("operator analysis", e);
+  op->far_per_row = (double)h.far / (double)n;
+  bool sym = want_sym && !h.bad;
+  if (want_sym && !sym) {
+    hipFree(op->rowptr_u);
+    op->rowptr_u = nullptr;
+  }
+  if (sym) {
+    e = device_scan_inclusive(op->rowptr_u + 1, n, st);
+    int32_t nu32 = 0;
+    if (e == hipSuccess) e = hipMemcpy(&nu32, op->rowptr_u + n, 4, hipMemcpyDeviceToHost);
+    const size_t nu = (size_t)nu32;
+    op->nnz_u = (int64_t)nu;
+    if (e == hipSuccess) e = hipMalloc((void **)&op->colind_u, (nu + kCsrPad) * 4);
+    if (e == hipSuccess) e = hipMalloc(&op->vals_u, (nu + kCsrPad) * es);
+    if (e == hipSuccess) e = hipMemsetAsync(op->colind_u + nu, 0, kCsrPad * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync((char *)op->vals_u + nu * es, 0, kCsrPad * es, st);
+    if (e != hipSuccess) return hip_fail("upper triangle", e);
+    if (dtype == SLQ_F64) slqb::k_upper_fill<double><<<grow, brow, 0, st>>>((int)n, op->rowptr, op->colind, (const double *)op->vals, op->rowptr_u, op->colind_u, (double *)op->vals_u);
+    else slqb::k_upper_fill<float><<<grow, brow, 0, st>>>((int)n, op->rowptr, op->colind, (const float *)op->vals, op->rowptr_u, op->colind_u, (float *)op->vals_u);
+  }
+  if (env_int("SLQ_DEBUG", 0) != 0)
+    fprintf(stderr, "[slq] csr n=%lld nnz=%lld reordered=1 rms in-chunk |i-j| = %.1f, far gathers per row %.2f (built on the device)\n", (long long)n, (long long)nnz,
+            op->rms_dist, op->far_per_row);
+  clk.lap("  device: stored CSR, upper triangle");
+  // the tiles' stream over the full rows
+  DeviceStream full;
+  int rc = device_build_stream(ctx, dtype, 1, n, op->rowptr, op->colind, op->vals, d_tr, ntiles, false, 0.0, true, full);
+  if (rc != 0) return rc < 0 ? rc : fail(SLQ_EHIP, "tile stream declined");
+  op->tile_desc = full.desc, op->tile_rec = full.rec;
+  op->tile_desc_bytes = full.desc_bytes, op->tile_rec_bytes = full.rec_bytes;
+  op->tiles.tile_ptr = full.tile_ptr;
+  op->tiles.max_cols = full.max_lines;
+  for (int x = 0; x < 9; ++x) op->tiles.xcd_tile[x] = xcd_tile[x];
+  op->tiles_ringed = true;
+  op->merged_lock = new (std::nothrow) std::mutex();
+  clk.lap("  device: tile stream");
+  if (sym) {
+    if (rg.joinable()) rg.join();
+    if (rg_failed) return fail(SLQ_ENOMEM, "host worker failed (upper-triangle tiles)");
+    if (!regroup) tile_row_u = tile_row;
+    for (int x = 0; x < 9; ++x) op->xcd_tile_u[x] = xcd_u[x];
+    const int ntu = (int)tile_row_u.size() - 1;
+    if (env_int("SLQ_DEBUG", 0) != 0)
+      fprintf(stderr, "[slq] tiles: upper-triangle stream on %d tiles of %.2f rows (base: %d of %.2f)\n", ntu, (double)n / (double)ntu, ntiles, (double)n / (double)ntiles);
+    DevBuf d_tru;
+    e = d_tru.alloc(tile_row_u.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_tru.p, tile_row_u.data(), tile_row_u.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail("upper-triangle tiles", e);
+    DeviceStream us;
+    rc = device_build_stream(ctx, dtype, 1, n, op->rowptr_u, op->colind_u, op->vals_u, d_tru.as<int32_t>(), ntu, env_int("SLQ_RING_PAD_ROWS", 1) != 0,
+                             kTileAlphaMergedColsPerRow, false, us);
+    if (rc < 0) return rc;
+    op->tile_max_lines_u = us.max_lines;
+    op->upper_per_row = (double)us.sum_lines / (double)n;
+    if (env_int("SLQ_DEBUG", 0) != 0)
+      fprintf(stderr, "[slq] tiles: upper triangle: %.2f distinct panel rows per row, longest list %d (full rows: %d)\n", op->upper_per_row, us.max_lines, full.max_lines);
+    if (rc == 0) {
+      op->tile_desc_u = us.desc, op->tile_rec_u = us.rec;
+      op->tile_desc_u_bytes = us.desc_bytes, op->tile_rec_u_bytes = us.rec_bytes;
+      op->tile_u_padded = us.padded;
+    }
+    clk.lap("  device: upper tile stream");
+  }
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail("operator build", e);
+  return SLQ_OK;
+}
+
+// SLQ_DEVICE_BUILD=2: 0 when everything two operators over the same matrix keep is the same, else the number of the first item that is not
+static int operators_differ(const slq_operator *a, const slq_operator *b) {
+  const size_t es = esize(a->dtype);
+  auto same = [](const void *x, const void *y, size_t bytes) {
+    if (!x || !y) return x == y;
+    std::vector<char> hx(bytes), hy(bytes);
+    if (hipMemcpy(hx.data(), x, bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hy.data(), y, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return memcmp(hx.data(), hy.data(), bytes) == 0;
+  };
+  const size_t n = (size_t)a->n, nnz = (size_t)a->nnz;
+  if (a->n != b->n || a->nnz != b->nnz || a->nnz_u != b->nnz_u || a->dtype != b->dtype) return 1;
+  if (!a->perm_h || !b->perm_h || *a->perm_h != *b->perm_h) return 2;
+  if (!same(a->perm_d, b->perm_d, n * 4) || !same(a->inv_perm_d, b->inv_perm_d, n * 4)) return 3;
+  if (!same(a->rowptr, b->rowptr, (n + 1) * 4)) return 4;
+  if (!same(a->colind, b->colind, (nnz + kCsrPad) * 4)) return 5;
+  if (!same(a->vals, b->vals, (nnz + kCsrPad) * es)) return 6;
+  if (a->far_per_row != b->far_per_row || a->rms_dist != b->rms_dist) return 7;
+  if ((a->rowptr_u == nullptr) != (b->rowptr_u == nullptr)) return 8;
+  if (a->rowptr_u) {
+    const size_t nu = (size_t)a->nnz_u;
+    if (!same(a->rowptr_u, b->rowptr_u, (n + 1) * 4)) return 9;
+    if (!same(a->colind_u, b->colind_u, (nu + kCsrPad) * 4)) return 10;
+    if (!same(a->vals_u, b->vals_u, (nu + kCsrPad) * es)) return 11;
+  }
+  for (int x = 0; x < 9; ++x)
+    if (a->tiles.xcd_tile[x] != b->tiles.xcd_tile[x] || a->xcd_tile_u[x] != b->xcd_tile_u[x]) return 12;
+  const size_t nt = (size_t)a->tiles.xcd_tile[8];
+  if (!same(a->tiles.tile_row, b->tiles.tile_row, (nt + 1) * 4) || !same(a->tiles.tile_ptr, b->tiles.tile_ptr, (nt + 1) * 4)) return 13;
+  if (a->tiles.max_cols != b->tiles.max_cols || a->tiles_ringed != b->tiles_ringed) return 14;
+  if (a->tile_desc_bytes != b->tile_desc_bytes || a->tile_rec_bytes != b->tile_rec_bytes) return 15;
+  if (!same(a->tile_desc, b->tile_desc, a->tile_desc_bytes)) return 16;
+  if (!same(a->tile_rec, b->tile_rec, a->tile_rec_bytes)) return 17;
+  if (a->tile_max_lines_u != b->tile_max_lines_u || a->upper_per_row != b->upper_per_row || a->tile_u_padded != b->tile_u_padded) return 18;
+  if ((a->tile_desc_u == nullptr) != (b->tile_desc_u == nullptr)) return 19;
+  if (a->tile_desc_u) {
+    if (a->tile_desc_u_bytes != b->tile_desc_u_bytes || a->tile_rec_u_bytes != b->tile_rec_u_bytes) return 20;
+    if (!same(a->tile_desc_u, b->tile_desc_u, a->tile_desc_u_bytes)) return 21;
+    if (!same(a->tile_rec_u, b->tile_rec_u, a->tile_rec_u_bytes)) return 22;
+  }
+  return 0;
 }
 
 extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
@@ -1744,12 +2133,14 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
   const int64_t n = op->n, nnz = op->nnz;
   const size_t es = esize(op->dtype);
   const int32_t ntiles = op->tiles.xcd_tile[8];
+  auto drop = [](slq_operator::MergedStream &mm) {
+    for (void **q : {(void **)&mm.desc, (void **)&mm.rec, (void **)&mm.desc_u, (void **)&mm.rec_u}) {
+      if (*q) hipFree(*q);
+      *q = nullptr;
+    }
+  };
   try {
-    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz), tr((size_t)ntiles + 1);
-    std::vector<char> va((size_t)nnz * es);
-    if (hipMemcpy(rp.data(), op->rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    if (hipMemcpy(ci.data(), op->colind, (size_t)nnz * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    if (hipMemcpy(va.data(), op->vals, (size_t)nnz * es, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    std::vector<int32_t> tr((size_t)ntiles + 1);
     if (hipMemcpy(tr.data(), op->tiles.tile_row, ((size_t)ntiles + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
     // merged tile boundaries, chunk by chunk (a merged tile never straddles two XCD chunks; a chunk's last one may be short)
     std::vector<int32_t> mrow;
@@ -1759,40 +2150,92 @@ static bool ensure_ring_stream(slq_operator *op, int R) {
     }
     m.xcd_tile[8] = (int32_t)mrow.size();
     mrow.push_back((int32_t)n);
-    auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines, bool *pad) -> bool {
-      std::vector<int32_t> tp, tc, lc, si;
-      RawBuf<int32_t> desc;
-      RawBuf<char> rec;
-      int mx = 0;
-      build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
-      *max_lines = mx;
-      if (mx > kRingTileCols * R) return false;  // (cannot happen: a union of R lists of <= 36)
-      if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
-      else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
-      if (hipMalloc((void **)desc_d, desc.size() * 4) != hipSuccess) return false;
-      if (hipMalloc((void **)rec_d, rec.size()) != hipSuccess) return false;
-      return hipMemcpy(*desc_d, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(*rec_d, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
+    // the host's way (SLQ_DEVICE_BUILD=0, and the yardstick of SLQ_DEVICE_BUILD=2): the CSR comes back, lists and stream are built
+    // here and uploaded. sizes: bytes of desc, rec, desc_u, rec_u
+    auto build_host = [&](slq_operator::MergedStream &mm, size_t sizes[4]) -> bool {
+      std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz);
+      std::vector<char> va((size_t)nnz * es);
+      if (hipMemcpy(rp.data(), op->rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+      if (hipMemcpy(ci.data(), op->colind, (size_t)nnz * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+      if (hipMemcpy(va.data(), op->vals, (size_t)nnz * es, hipMemcpyDeviceToHost) != hipSuccess) return false;
+      auto upload = [&](const int32_t *rowptr, const int32_t *colind, const void *vals, int32_t **desc_d, char **rec_d, int *max_lines, bool *pad, size_t *sz) -> bool {
+        std::vector<int32_t> tp, tc, lc, si;
+        RawBuf<int32_t> desc;
+        RawBuf<char> rec;
+        int mx = 0;
+        build_tile_meta(n, rowptr, colind, mrow, tp, tc, lc, si, &mx);
+        *max_lines = mx;
+        if (mx > kRingTileCols * R) return false;  // (cannot happen: a union of R lists of <= 36)
+        if (op->dtype == SLQ_F64) build_ring_stream<double>(R, rowptr, (const double *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
+        else build_ring_stream<float>(R, rowptr, (const float *)vals, mrow, tp, tc, lc, si, desc, rec, pad);
+        sz[0] = desc.size() * 4, sz[1] = rec.size();
+        if (hipMalloc((void **)desc_d, desc.size() * 4) != hipSuccess) return false;
+        if (hipMalloc((void **)rec_d, rec.size()) != hipSuccess) return false;
+        return hipMemcpy(*desc_d, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemcpy(*rec_d, rec.data(), rec.size(), hipMemcpyHostToDevice) == hipSuccess;
+      };
+      bool ok = upload(rp.data(), ci.data(), va.data(), &mm.desc, &mm.rec, &mm.max_lines, nullptr, sizes);
+      if (ok && op->tile_desc_u && op->rowptr_u) {
+        const size_t nu = (size_t)op->nnz_u;
+        bool upad = env_int("SLQ_RING_PAD_ROWS", 1) != 0;
+        std::vector<int32_t> urp((size_t)n + 1), uci(nu);
+        std::vector<char> uva(nu * es);
+        ok = hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) == hipSuccess &&
+             upload(urp.data(), uci.data(), uva.data(), &mm.desc_u, &mm.rec_u, &mm.max_lines_u, &upad, sizes + 2);
+        mm.u_padded = ok && upad;
+      }
+      if (!ok) drop(mm);
+      return ok;
     };
-    bool ok = upload(rp.data(), ci.data(), va.data(), &m.desc, &m.rec, &m.max_lines, nullptr);
-    if (ok && op->tile_desc_u && op->rowptr_u) {
-      const size_t nu = (size_t)op->nnz_u;
-      bool upad = env_int("SLQ_RING_PAD_ROWS", 1) != 0;
-      std::vector<int32_t> urp((size_t)n + 1), uci(nu);
-      std::vector<char> uva(nu * es);
-      ok = hipMemcpy(urp.data(), op->rowptr_u, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-           hipMemcpy(uci.data(), op->colind_u, nu * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-           hipMemcpy(uva.data(), op->vals_u, nu * es, hipMemcpyDeviceToHost) == hipSuccess &&
-           upload(urp.data(), uci.data(), uva.data(), &m.desc_u, &m.rec_u, &m.max_lines_u, &upad);
-      m.u_padded = ok && upad;
-    }
-    if (!ok) {
-      for (void **q : {(void **)&m.desc, (void **)&m.rec, (void **)&m.desc_u, (void **)&m.rec_u}) {
-        if (*q) hipFree(*q);
-        *q = nullptr;
+    // on the device (slq_build.hpp): the operator's CSR never leaves it
+    size_t dsz[4] = {0, 0, 0, 0};
+    auto build_device = [&](slq_operator::MergedStream &mm) -> bool {
+      if (hipSetDevice(op->ctx->device) != hipSuccess) return false;
+      DevBuf d_mrow;
+      if (d_mrow.alloc(mrow.size() * 4) != hipSuccess) return false;
+      if (hipMemcpy(d_mrow.p, mrow.data(), mrow.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return false;
+      const int nm = (int)mrow.size() - 1;
+      DeviceStream f;
+      if (device_build_stream(op->ctx, op->dtype, R, n, op->rowptr, op->colind, op->vals, d_mrow.as<int32_t>(), nm, false, 0.0, false, f) != 0) return false;
+      mm.desc = f.desc, mm.rec = f.rec, mm.max_lines = f.max_lines;
+      dsz[0] = f.desc_bytes, dsz[1] = f.rec_bytes;
+      if (op->tile_desc_u && op->rowptr_u) {
+        DeviceStream g;
+        if (device_build_stream(op->ctx, op->dtype, R, n, op->rowptr_u, op->colind_u, op->vals_u, d_mrow.as<int32_t>(), nm, env_int("SLQ_RING_PAD_ROWS", 1) != 0, 0.0, false, g) != 0) {
+          drop(mm);
+          return false;
+        }
+        mm.desc_u = g.desc, mm.rec_u = g.rec, mm.max_lines_u = g.max_lines, mm.u_padded = g.padded;
+        dsz[2] = g.desc_bytes, dsz[3] = g.rec_bytes;
+      }
+      return true;
+    };
+    const int dev_mode = env_int("SLQ_RING_ORDER", 0) != 0 ? 0 : env_int("SLQ_DEVICE_BUILD", 1);
+    size_t hsz[4] = {0, 0, 0, 0};
+    if (dev_mode == 0) return build_host(m, hsz);
+    if (!build_device(m)) return false;
+    if (dev_mode == 2) {  // both, compared
+      slq_operator::MergedStream h;
+      bool same = build_host(h, hsz);
+      auto eq = [](const void *x, const void *y, size_t bytes) {
+        if (!x || !y) return x == y;
+        std::vector<char> hx(bytes), hy(bytes);
+        return hipMemcpy(hx.data(), x, bytes, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hy.data(), y, bytes, hipMemcpyDeviceToHost) == hipSuccess &&
+               memcmp(hx.data(), hy.data(), bytes) == 0;
+      };
+      for (int q = 0; q < 4 && same; ++q) same = hsz[q] == dsz[q];
+      same = same && h.max_lines == m.max_lines && h.max_lines_u == m.max_lines_u && h.u_padded == m.u_padded;
+      same = same && eq(h.desc, m.desc, dsz[0]) && eq(h.rec, m.rec, dsz[1]) && eq(h.desc_u, m.desc_u, dsz[2]) && eq(h.rec_u, m.rec_u, dsz[3]);
+      drop(h);
+      if (!same) {
+        fprintf(stderr, "[slq] SLQ_DEVICE_BUILD=2: the device-built stream of %d-merged tiles differs from the host-built one\n", R);
+        drop(m);
+        return false;
       }
     }
-    return ok;
+    return true;
   } catch (const std::bad_alloc &) {
     return false;
   }

@@ -21,7 +21,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def kernel_sources_sha256():
 	"""Same digest as bench.py:kernel_sources_sha256 - the bench line quotes a traffic figure only when it matches."""
 	h = hashlib.sha256()
-	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq_ring_fa.hpp", "primate_amd/csrc/slq.hip"):
+	for f in ("primate_amd/csrc/slq_common.hpp", "primate_amd/csrc/slq_kernels.hpp", "primate_amd/csrc/slq_ring.hpp", "primate_amd/csrc/slq_ring_fa.hpp", "primate_amd/csrc/slq_build.hpp", "primate_amd/csrc/slq.hip"):
 		h.update((ROOT / f).read_bytes())
 	return h.hexdigest()
 

@@ -1,7 +1,7 @@
 """What creating an operator costs on the host (reordering, tile clustering, uploads), for the operators of BASELINE.json's
 configs: the grids take the tiles, the random graph and the scattered band are turned away by the 256-cluster sample.
 
-    SLQ_DEBUG=1 python scripts/time_create.py
+    SLQ_DEBUG=1 python scripts/time_create.py        (SLQ_DEVICE_BUILD=0: everything on the host, as before r04)
 """
 import sys, time
 from pathlib import Path
@@ -37,6 +37,10 @@ for name, A in [("lap2d_1000", laplacian_2d(1000)), ("lap3d_100", laplacian_3d(1
 	t = time.perf_counter(); op = eng.DeviceOperator(A); ctx.synchronize(); dt = time.perf_counter() - t
 	t = time.perf_counter(); plan = eng.LanczosPlan(op, 256, 30, 3); ctx.synchronize(); dp = time.perf_counter() - t
 	print(f"{name}: operator create {dt:.3f} s (host-side checks of the scipy matrix alone: {prep*1e3:.1f} ms), plan create {dp:.3f} s, tiles {plan.describe()['tiles']}", flush=True)
+	plan.close()
+	## narrow panels: the first plan of 64 probes has the 2-merged tiles' streams built (r04: on the device, from the operator's own arrays)
+	t = time.perf_counter(); plan = eng.LanczosPlan(op, 64, 30, 3); ctx.synchronize(); dp = time.perf_counter() - t
+	print(f"    first plan of 64 probes: {dp:.3f} s, tiles {plan.describe()['tiles']}", flush=True)
 	plan.close(); op.close()
 	## what the drivers pay: MatrixFunction over the same matrix twice (r04: operators are cached by content of the sparse matrix)
 	from primate_amd.operators import MatrixFunction

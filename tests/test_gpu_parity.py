@@ -1200,3 +1200,57 @@ def test_tall_skinny_mfma_products(eng):
 		with pytest.raises(ValueError):
 			dA.add_product(0, dA, 1, np.zeros((ma, 3)))  # overlapping in/out columns
 		dA.close(), dB.close()
+
+
+@pytest.mark.gpu
+def test_device_built_streams_equal_the_host_built_ones(oracle, eng, monkeypatch):
+	"""r04 (slq_build.hpp): operators with ring-sized tiles have their stored CSR, upper triangle and tile streams
+	built on the device. SLQ_DEVICE_BUILD=2 builds every array both ways and the library raises if one byte differs; here for a
+	5-point and a 7-point grid, weighted symmetric and non-symmetric values (the latter: no upper triangle), fp64 and fp32, and the
+	2- and 4-merged tiles of narrow panels; the values of a run are then checked against the oracle as everywhere else."""
+	import scipy.sparse as sp
+
+	monkeypatch.setenv("SLQ_TILES", "2")
+	monkeypatch.setenv("SLQ_DEVICE_BUILD", "2")
+	rng = np.random.default_rng(11)
+
+	def weighted(A, symmetric):
+		C = sp.coo_matrix(A)
+		w = rng.uniform(0.5, 1.5, C.nnz)
+		W = sp.csr_matrix((w, (C.row, C.col)), shape=A.shape)
+		W = ((W + W.T) * 0.5).tocsr() if symmetric else W
+		W = (W + sp.diags(np.asarray(abs(W).sum(axis=1)).ravel() + 1.0)).tocsr()
+		W.sort_indices()
+		return W
+
+	cases = [("lap2d_150", laplacian_2d(150), True), ("lap3d_30", laplacian_3d(30), True), ("lap3d_24_f32", laplacian_3d(24, np.float32), True),
+	         ("weighted 2-D", weighted(laplacian_2d(120), True), True), ("weighted 3-D, not symmetric", weighted(laplacian_3d(22), False), False)]  # fmt: skip
+	for name, A, sym in cases:
+		op = eng.DeviceOperator(A)  # (raises when the two builds differ)
+		for P in (130, 64, 32) if A.dtype == np.float64 else (130, 64):  # (panel rows of 512, 256 and 128 bytes: unmerged, 2- and 4-merged tiles)
+			plan = eng.LanczosPlan(op, P, 12, 3)
+			info = plan.describe()
+			assert info["tiles"] == 2 and info["upper_alpha"] == int(sym), (name, P, info)
+			plan.generate_probes("rademacher", seed=3)
+			V = plan.get_probes()[:, [0, P - 1]]
+			plan.run()
+			if sym:
+				q = plan.quadrature("log")
+				ref = oracle.quad_batch(sp.csr_matrix(A, dtype=np.float64), np.asfortranarray(V, dtype=np.float64), 12, 3, fun="log", fresh_q=True)
+				assert np.max(np.abs(q[[0, P - 1]] / ref - 1.0)) < (1e-9 if A.dtype == np.float64 else 2e-4), (name, P)
+			else:  # (the oracle's recurrence never checks symmetry either: alpha and beta)
+				a, b, _ = plan.tridiag()
+				for k, c in enumerate((0, P - 1)):
+					ar, br, Qr = np.zeros(13), np.zeros(13), np.zeros((A.shape[0], 3), order="F")
+					oracle.lanczos(A, V[:, k].copy(), 12, 1e-8, 3, ar, br, Qr)
+					np.testing.assert_allclose(a[c][:12], ar[:12], rtol=1e-10, atol=1e-10)
+					np.testing.assert_allclose(b[c][1:12], br[1:12], rtol=1e-10, atol=1e-10)
+			plan.close()
+		op.close()
+	## and one operator the device build leaves to the host (no tiles: a random graph) still builds
+	G = sp.random(6000, 6000, density=0.002, random_state=5, format="csr")
+	G = (G + G.T + sp.identity(6000) * 10.0).tocsr()
+	op = eng.DeviceOperator(G)
+	plan = eng.LanczosPlan(op, 8, 5, 0)
+	assert plan.describe()["tiles"] == 0
+	plan.close(), op.close()
