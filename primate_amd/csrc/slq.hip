@@ -3352,9 +3352,10 @@ template <typename F, int L>
 static inline void launch_reorth_update_kernel(slq_plan *p, dim3 gS, size_t lds, hipStream_t st, int j, int i0, int rc, int archive, bool axpy = false) {
   if constexpr (std::is_same<F, double>::value) {
     if (p->ring32_on) {
-      const size_t lds32 = sizeof(double) * kWaves * 64 * 4 + (size_t)rc * p->PW * sizeof(double);
+      const size_t lds32 = sizeof(double) * kWaves * 64 * 4 + (size_t)rc * p->PW * sizeof(double) + (2 * (size_t)rc + 1) * sizeof(int);
       k_reorth_update32<L><<<gS, dim3(kBlock), lds32, st>>>(p->n, (double *)p->ring, p->slot_stride, p->S, j, i0, rc,
-                                                          p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, p->ring32, p->slot_stride, p->S32, archive);
+                                                          p->st.gamma + (size_t)i0 * p->bpad, p->part, p->bpad, p->ring32, p->slot_stride, p->S32, archive,
+                                                          p->sweep_cols_d, p->sweep_skip ? 1 : 0);
       return;
     }
   }

@@ -1903,17 +1903,39 @@ __global__ __launch_bounds__(kBlock) void k_reorth_dot32(
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void k_reorth_update32(
     int n, double *ring, int64_t slot_stride, int S, int j, int i0, int r, const double *__restrict__ gamma /* [r][bpad], offset to i0 */,
-    double *__restrict__ partN, int bpad, float *ring32, int64_t stride32, int S32, int archive /* w is final: store it as fp32 too */) {
+    double *__restrict__ partN, int bpad, float *ring32, int64_t stride32, int S32, int archive /* w is final: store it as fp32 too */,
+    unsigned long long *__restrict__ cols_stat, int skip_zero_cols /* as k_reorth_update */) {
   constexpr int PW = Geo32<LPR>::PW, LR = Geo32<LPR>::LR, RW = Geo32<LPR>::RW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double *red = (double *)lds_raw;               // kWaves*64*4 doubles
   double *gl = red + kWaves * 64 * 4;            // r * PW
+  int *fl = (int *)(gl + (size_t)r * PW);        // r flags, then the list of the columns to read and its length (r + 1 ints)
+  int *lst = fl + r;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / LR, c4 = lane % LR;
   const int panel = blockIdx.y;
   const int64_t poff = (int64_t)panel * n * PW + c4 * 4;
-  for (int t = threadIdx.x; t < r * PW; t += kBlock) gl[t] = gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+  for (int t = threadIdx.x; t < r; t += kBlock) fl[t] = 0;
   __syncthreads();
+  for (int t = threadIdx.x; t < r * PW; t += kBlock) {
+    const double gv = gamma[(int64_t)(t / PW) * bpad + panel * PW + (t % PW)];
+    gl[t] = gv;
+    if (gv != 0.0) fl[t / PW] = 1;
+  }
+  __syncthreads();
+  // columns nobody of this panel projects on are not read (k_reorth_update, r04): the list of the others, ascending - the order of the subtractions is kept
+  if (threadIdx.x == 0) {
+    int m = 0;
+    for (int i = 0; i < r; ++i)
+      if (fl[i] || !skip_zero_cols) lst[m++] = i;
+    lst[r] = m;
+    if (cols_stat && blockIdx.x == 0) {
+      atomicAdd(cols_stat, (unsigned long long)m);
+      atomicAdd(cols_stat + 1, (unsigned long long)r);
+    }
+  }
+  __syncthreads();
+  const int nlive = lst[r];
   double *W = ring + (int64_t)((j + 1) % S) * slot_stride + poff;
   float *W32 = ring32 + (int64_t)ring_slot(j + 1, S32) * stride32 + poff;
   double nacc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1922,18 +1944,23 @@ __global__ __launch_bounds__(kBlock) void k_reorth_update32(
     const int64_t ro = (int64_t)row * PW;
     const d2a_t wa = *(const d2a_t *)(W + ro), wb = *(const d2a_t *)(W + ro + 2);
     double w[4] = {wa[0], wa[1], wb[0], wb[1]};
-    int i = 0;
-    for (; i + 4 <= r; i += 4) {  // four columns' loads in flight
+    int ii = 0;
+    for (; ii + 4 <= nlive; ii += 4) {  // four columns' loads in flight
       double u[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - i - q, i0 + i + q, u[q]);
+      int ci[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const d2a_t ga = *(const d2a_t *)(gl + (i + q) * PW + c4 * 4), gb = *(const d2a_t *)(gl + (i + q) * PW + c4 * 4 + 2);
+        ci[q] = lst[ii + q];
+        ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - ci[q], i0 + ci[q], u[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const d2a_t ga = *(const d2a_t *)(gl + ci[q] * PW + c4 * 4), gb = *(const d2a_t *)(gl + ci[q] * PW + c4 * 4 + 2);
         w[0] -= ga[0] * u[q][0]; w[1] -= ga[1] * u[q][1]; w[2] -= gb[0] * u[q][2]; w[3] -= gb[1] * u[q][3];
       }
     }
-    for (; i < r; ++i) {
+    for (; ii < nlive; ++ii) {
+      const int i = lst[ii];
       double u[4];
       ring_column4(ring, slot_stride, S, ring32, stride32, S32, poff + ro, j - i0 - i, i0 + i, u);
       const d2a_t ga = *(const d2a_t *)(gl + i * PW + c4 * 4), gb = *(const d2a_t *)(gl + i * PW + c4 * 4 + 2);
