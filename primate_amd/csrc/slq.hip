@@ -1162,8 +1162,11 @@ static bool device_equals_host(const void *dev, const void *host, size_t bytes) 
 
 // plain != 0: rows stay in the caller's order and no derived copy (upper triangle, tiles) is built - for operators whose
 // values change after creation (the affine operator)
+// dev_*: the same CSR already on the device (slq_csr_create_device): the device-side build reads it in place, and `vals` may then be null
+// (the values come back to the host only if the host has to build the operator after all)
+struct DeviceCsr { const int32_t *rp = nullptr, *ci = nullptr; const void *va = nullptr; };
 static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain, int host_build = 0);
+                           const void *vals, slq_operator **out, int plain, int host_build = 0, DeviceCsr dev = DeviceCsr());
 
 extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nnz,
                               const int32_t *rowptr, const int32_t *colind, const void *vals,
@@ -1172,11 +1175,11 @@ extern "C" int slq_csr_create(slq_context *ctx, int dtype, int64_t n, int64_t nn
 }
 
 static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain, int host_build);
+                           const void *vals, slq_operator **out, int plain, int host_build, DeviceCsr dev);
 static int csr_create_impl(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain, int host_build) {
+                           const void *vals, slq_operator **out, int plain, int host_build, DeviceCsr dev) {
   try {  // (host-side allocations of the analysis: no C++ exception crosses the C boundary)
-    return csr_create_body(ctx, dtype, n, nnz, rowptr, colind, vals, out, plain, host_build);
+    return csr_create_body(ctx, dtype, n, nnz, rowptr, colind, vals, out, plain, host_build, dev);
   } catch (const std::bad_alloc &) {
     if (out) *out = nullptr;
     return fail(SLQ_ENOMEM, "host allocation failed while analysing the operator");
@@ -1191,17 +1194,25 @@ static int csr_finish_on_device(slq_context *ctx, slq_operator *op, int dtype, i
                                 const int32_t xcd_tile[9], PhaseClock &clk);
 static int operators_differ(const slq_operator *a, const slq_operator *b);
 static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind,
-                           const void *vals, slq_operator **out, int plain, int host_build) {
+                           const void *vals, slq_operator **out, int plain, int host_build, DeviceCsr dev) {
   if (!ctx || !out) return fail(SLQ_EINVAL, "ctx/out is NULL");
   *out = nullptr;
   SLQ_TRY(check_dtype(dtype));
   if (n <= 0 || n >= (int64_t)1 << 31 || nnz < 0 || nnz >= (int64_t)1 << 31)
     return fail(SLQ_EINVAL, "CSR shape out of range for int32 indices (n=%lld, nnz=%lld)",
                 (long long)n, (long long)nnz);
-  if (!rowptr || (nnz > 0 && (!colind || !vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
+  if (!rowptr || (nnz > 0 && (!colind || (!vals && !dev.va)))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
   if (rowptr[0] != 0 || rowptr[n] != nnz)
     return fail(SLQ_EINVAL, "rowptr[0] must be 0 and rowptr[n] must equal nnz");
   PhaseClock clk;
+  std::vector<char> vals_back;  // the values of a device-resident CSR, fetched when the host needs them
+  auto need_host_vals = [&]() -> hipError_t {
+    if (vals || nnz == 0) return hipSuccess;
+    vals_back.resize((size_t)nnz * esize(dtype));
+    const hipError_t he = hipMemcpy(vals_back.data(), dev.va, vals_back.size(), hipMemcpyDeviceToHost);
+    vals = vals_back.data();
+    return he;
+  };
   for (int64_t i = 0; i < n; ++i)
     if (rowptr[i + 1] < rowptr[i]) return fail(SLQ_EINVAL, "rowptr is not non-decreasing at %lld", (long long)i);
   {
@@ -1297,13 +1308,19 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   DevBuf o_rp, o_ci, o_va;       // the caller's CSR on the device (scratch of the build)
   UploadQueue early(ctx->device);  // (declared after what it fills: joined first)
   bool early_started = false;
-  if (dev_mode != 0 && try_tiles && tmode == 2 && reorder_mode != 0 && env_int("SLQ_RING_ORDER", 0) == 0) {
+  const int32_t *src_rp = nullptr, *src_ci = nullptr;  // where the device-side build reads the caller's CSR
+  const void *src_va = nullptr;
+  if (dev_mode != 0 && try_tiles && tmode == 2 && reorder_mode != 0 && env_int("SLQ_RING_ORDER", 0) == 0 && dev.va) {
+    src_rp = dev.rp, src_ci = dev.ci, src_va = dev.va;  // in place (slq_csr_create_device)
+    early_started = true;
+  } else if (dev_mode != 0 && try_tiles && tmode == 2 && reorder_mode != 0 && env_int("SLQ_RING_ORDER", 0) == 0) {
     hipError_t ee = o_rp.alloc((size_t)(n + 1) * 4);
     if (ee == hipSuccess) ee = o_ci.alloc((size_t)nnz * 4);
     if (ee == hipSuccess) ee = o_va.alloc((size_t)nnz * esize(dtype));
     if (ee != hipSuccess) return fail(ee == hipErrorOutOfMemory ? SLQ_ENOMEM : SLQ_EHIP, "CSR upload: %s", hipGetErrorString(ee));
     early.push({{o_rp.p, rowptr, (size_t)(n + 1) * 4}, {o_ci.p, colind, (size_t)nnz * 4}, {o_va.p, vals, (size_t)nnz * esize(dtype)}});
     early_started = true;
+    src_rp = o_rp.as<int32_t>(), src_ci = o_ci.as<int32_t>(), src_va = o_va.p;
   }
   const double tile_limit = kTileMaxColsPerRow;
   std::vector<int32_t> tile_row;
@@ -1404,9 +1421,10 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
   if (op->rms_dist < 0.0 && nnz > 0) op->rms_dist = mean_dist(nullptr);
   clk.lap("reorder decision");
   if (early_started && have_tiles && op->perm_h) {
-    const int rc = csr_finish_on_device(ctx, op, dtype, n, nnz, rowptr, colind, o_rp.as<int32_t>(), o_ci.as<int32_t>(), o_va.p, early, tile_row, xcd_tile, clk);
+    const int rc = csr_finish_on_device(ctx, op, dtype, n, nnz, rowptr, colind, src_rp, src_ci, src_va, early, tile_row, xcd_tile, clk);
     if (rc != SLQ_OK) return rc;
     if (dev_mode == 2) {  // the same operator built on the host: every array must be the same
+      if (need_host_vals() != hipSuccess) return fail(SLQ_EHIP, "CSR values: copy back failed");
       slq_operator *ref = nullptr;
       const int rr = csr_create_impl(ctx, dtype, n, nnz, rowptr, colind, vals, &ref, plain, 1);
       if (rr != SLQ_OK) return rr;
@@ -1423,6 +1441,7 @@ static int csr_create_body(slq_context *ctx, int dtype, int64_t n, int64_t nnz, 
     early.wait();
     o_rp.release(), o_ci.release(), o_va.release();
   }
+  if (need_host_vals() != hipSuccess) return fail(SLQ_EHIP, "CSR values: copy back failed");
   // From here on every array goes to the device through `up` while the next one is being built; the buffers it reads are
   // declared before it and nothing returns without up.wait() (its destructor, at the latest).
   std::vector<int32_t> inv_keep;                  // stored row of every caller row (reordered operators)
@@ -1834,23 +1853,22 @@ extern "C" int slq_csr_create_device(slq_context *ctx, int dtype, int64_t n, int
   if (!d_rowptr || (nnz > 0 && (!d_colind || !d_vals))) return fail(SLQ_EINVAL, "CSR arrays are NULL");
   HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->dead) return fail(SLQ_EINVAL, "the context has been destroyed");
-  // The operator is built the way slq_csr_create builds it - validated, reordered, with its upper triangle and its tiles -
-  // and all of that is decided on the host: one copy of the CSR arrays comes back (12-16 bytes per nonzero, once), the operator's
-  // own storage is uploaded from it, and the caller's arrays are not referenced after the call.
-  const size_t es = esize(dtype);
+  // The operator is built the way slq_csr_create builds it - validated, reordered, with its upper triangle and its tiles. Order and
+  // tiles are decided on the host, from the index arrays (4 bytes per nonzero come back, once); what the operator stores is then built
+  // on the device straight from the caller's arrays (slq_build.hpp) - the values come back only for operators without ring tiles, whose
+  // storage the host builds. The caller's arrays are not referenced after the call.
   std::vector<int32_t> rp, ci;
-  std::vector<char> va;
   try {
     rp.resize((size_t)n + 1);
     ci.resize((size_t)nnz);
-    va.resize((size_t)nnz * es);
   } catch (const std::bad_alloc &) {
     return fail(SLQ_ENOMEM, "host allocation failed");
   }
   HIP_TRY(hipMemcpy(rp.data(), d_rowptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
   if (nnz) HIP_TRY(hipMemcpy(ci.data(), d_colind, (size_t)nnz * 4, hipMemcpyDeviceToHost));
-  if (nnz) HIP_TRY(hipMemcpy(va.data(), d_vals, (size_t)nnz * es, hipMemcpyDeviceToHost));
-  return csr_create_impl(ctx, dtype, n, nnz, rp.data(), ci.data(), va.data(), out, 0);
+  DeviceCsr dev;
+  dev.rp = d_rowptr, dev.ci = d_colind, dev.va = d_vals;
+  return csr_create_impl(ctx, dtype, n, nnz, rp.data(), ci.data(), nullptr, out, 0, 0, dev);
 }
 
 extern "C" int slq_csr_gram_create(slq_context *ctx, int dtype, int64_t mrows, int64_t ncols, int64_t nnz, const int32_t *rowptr,

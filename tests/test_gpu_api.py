@@ -538,6 +538,22 @@ def test_device_resident_csr_operator_is_built_like_a_host_one():
 		p.run()
 	assert np.array_equal(pd.quadrature("log"), ph.quadrature("log"))
 	pd.close(), ph.close(), op_d.close(), op_h.close()
+	## r04: with ring tiles the stored arrays are built on the device straight from the tensor's arrays (the values never visit the host);
+	## an operator without tiles - a small random graph - is still built on the host, from values fetched then
+	import scipy.sparse as sp
+
+	G = sp.random(5000, 5000, density=0.002, random_state=3, format="csr")
+	G = (G + G.T + sp.identity(5000) * 8.0).tocsr()
+	G.sort_indices()
+	Tg = torch.sparse_csr_tensor(torch.from_numpy(G.indptr.astype(np.int64)), torch.from_numpy(G.indices.astype(np.int64)), torch.from_numpy(G.data), size=G.shape).cuda()
+	og, oh = eng.DeviceOperator(Tg), eng.DeviceOperator(G)
+	pg, ph = eng.LanczosPlan(og, 12, 10, 3), eng.LanczosPlan(oh, 12, 10, 3)
+	assert pg.describe() == ph.describe() and pg.describe()["tiles"] == 0
+	for p in (pg, ph):
+		p.generate_probes("rademacher", seed=5)
+		p.run()
+	assert np.array_equal(pg.quadrature("log"), ph.quadrature("log"))
+	pg.close(), ph.close(), og.close(), oh.close()
 	bad = torch.sparse_csr_tensor(torch.tensor([0, 1, 2]), torch.tensor([0, 5]), torch.tensor([1.0, 1.0]), size=(2, 2), check_invariants=False).cuda()
 	with pytest.raises(ValueError):
 		eng.DeviceOperator(bad)
