@@ -5,6 +5,9 @@
 Lanczos basis, then the numer/denom/running-mean accumulation (`slq_diag_update`). Everything else
 (plain matrices, adaptive stopping rules, callbacks) follows the reference loop on the host with the
 operator product delegated to `A @ v`.
+
+`xdiag(A, m)` is the exchangeable estimator, re-derived here as an average of leave-one-out estimates (`_exchangeable_diagonal`) and pinned by the
+reference's own output (tests/golden: `xdiag_m40`).
 """
 
 from __future__ import annotations
@@ -89,3 +92,48 @@ def diag(
 		result.estimate, result.nit = estimator.estimate, len(estimator)
 		return (estimator.estimate, result)
 	return estimator.estimate
+
+
+def _exchangeable_diagonal(W: np.ndarray, Y: np.ndarray, Q: np.ndarray, Z: np.ndarray, R: np.ndarray) -> np.ndarray:
+	"""The XDiag estimate from one sketch (Epperly, Tropp & Webber, "XTrace: making the most of every sample", section on diagonals;
+	what src/primate/diagonal.py:99-138 evaluates), written as the average of k leave-one-out estimates.
+
+	W: the k probes; Y = A W = Q R; Z = A^T Q. For probe i let Q_(i) span the sketch WITHOUT column i: Q_(i) Q_(i)^T = Q (I - s_i s_i^T) Q^T with
+	s_i the i-th row of R^{-1} scaled to unit length (the same downdate `trace._leave_one_out_estimates` uses). Estimate i is the
+	diagonal of A on that span plus probe i's own Girard-Hutchinson term on what is left,
+
+	    d_i = diag(Q_(i) Q_(i)^T A) + w_i * ((I - Q_(i) Q_(i)^T) A w_i),
+
+	and d = mean_i d_i. With t_i = Q^T A w_i (column i of T = Z^T W):
+	  * diag(Q_(i) Q_(i)^T A) = rowsum(Q * Z) - (Q s_i) * (Z s_i): the first part is common to all i, the second averages to rowsum((QS) * (ZS)) / k;
+	  * (I - Q_(i) Q_(i)^T) A w_i = y_i - Q t_i + (Q s_i)(s_i . t_i): column i of the residual matrix below.
+	Everything of size n is a product of n x k with k x k matrices."""
+	from scipy.linalg import solve_triangular
+
+	k = W.shape[1]
+	R_inv = solve_triangular(R, np.eye(k))
+	S = R_inv.T / np.linalg.norm(R_inv, axis=1)  # unit columns: the directions the k downdates remove
+	T = Z.T @ W
+	QS, ZS = Q @ S, Z @ S
+	resid = Y - Q @ T + QS * np.einsum("ij,ij->j", S, T)  # column i: what probe i sees of A outside its own leave-one-out span
+	on_span = np.einsum("ij,ij->i", Q, Z) - np.einsum("ij,ij->i", QS, ZS) / k
+	off_span = np.einsum("ij,ij->i", W, resid) / k
+	return on_span + off_span
+
+
+def xdiag(A, m: Optional[int] = None, pdf: str = "sphere", seed: Union[int, np.random.Generator, None] = None) -> np.ndarray:
+	"""Exchangeable diagonal estimator with the reference's signature and probe stream (src/primate/diagonal.py:99-138): about m / 2 products
+	with A for the sketch and m / 2 with A^T for its image, then `_exchangeable_diagonal` (m = None: the full budget of 2 n).
+
+	Over a `MatrixFunction` the two products are the hot path: each is ONE lock-step Lanczos batch of m / 2 columns on the GPU (f(A) W from the
+	retained bases, then f(A) Q); the k x k algebra around them stays on the host like the reference's."""
+	assert is_valid_operator(A) or isinstance(A, np.ndarray), "A must be a matrix or a linear operator"
+	n = A.shape[0]
+	budget = 2 * n if m is None else min(int(m) + int(m) % 2, 2 * n)  # (rounded up to an even count, at most 2 n: diagonal.py:106-107)
+	k = budget // 2
+	rng = np.random.default_rng(seed=seed)
+	W = isotropic(pdf=pdf, seed=rng)(size=(n, k))
+	Y = np.asarray(A @ W)
+	Q, R = np.linalg.qr(Y, mode="reduced")
+	Z = np.asarray(A.T @ Q)
+	return _exchangeable_diagonal(W, Y, Q, Z, R)

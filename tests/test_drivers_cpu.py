@@ -55,6 +55,28 @@ def test_diag_matches_reference(gd):
 	np.testing.assert_allclose(diag(A, converge="tolerance", atol=0.0, rtol=0.01, seed=3), gd["diag_tol"], rtol=1e-13)
 
 
+def test_xdiag_matches_reference(gd):
+	"""The exchangeable diagonal estimator (src/primate/diagonal.py:99-138), re-derived as an average of leave-one-out estimates: the reference's output for
+	the same seed, the budget rounding (odd m rounds up, m is capped at 2 n), and - as an estimator - far closer to the diagonal than plain Girard-Hutchinson at
+	the same number of products when the spectrum decays."""
+	from primate_amd.diagonal import diag, xdiag
+
+	A = gd["A"]
+	n = A.shape[0]
+	np.testing.assert_allclose(xdiag(A, m=40, seed=1234), gd["xdiag_m40"], rtol=1e-12, atol=1e-13)
+	np.testing.assert_array_equal(xdiag(A, m=39, seed=5), xdiag(A, m=40, seed=5))
+	np.testing.assert_array_equal(xdiag(A, m=10 * n, seed=5), xdiag(A, seed=5))
+	for pdf in ("rademacher", "normal"):
+		assert xdiag(A, m=40, pdf=pdf, seed=2).shape == (n,)
+	## where the estimator earns its products: a spectrum that decays (the sketch captures most of the matrix, the probes only see the rest)
+	rng = np.random.default_rng(0)
+	U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+	B = (U * 0.7 ** np.arange(n)) @ U.T
+	err_x = np.linalg.norm(xdiag(B, m=40, seed=8) - B.diagonal())
+	err_g = np.linalg.norm(diag(B, converge="count", count=40, seed=8) - B.diagonal())
+	assert err_x < 0.05 * err_g, (err_x, err_g)
+
+
 def test_knee_criterion_and_update_trinv(gd):
 	from primate_amd.estimators import KneeCriterion, MeanEstimator, convergence_criterion
 	from primate_amd.linalg import update_trinv

@@ -176,7 +176,7 @@ def test_quadrature_api():
 
 
 def test_drivers_over_matrix_function(golden):
-	"""diag / hutchpp / xtrace over a MatrixFunction: the reference's drivers ran over the oracle
+	"""diag / hutchpp / xtrace / xdiag over a MatrixFunction: the reference's drivers ran over the oracle
 	("injected" golden, full reorth so the stale-ring quirk is absent: _matvec clears Q)."""
 	from pathlib import Path
 
@@ -199,6 +199,15 @@ def test_drivers_over_matrix_function(golden):
 	assert hutchpp(M0, m=24, seed=1234) == pytest.approx(float(gd["mf0_hutchpp_m24"]), rel=1e-8)
 	assert xtrace(M, batch=12, seed=1234) == pytest.approx(float(gd["mf_xtrace_b12"]), rel=1e-7)
 	assert xtrace(M, batch=16, seed=5, count=48) == pytest.approx(float(gd["mf_exact_trace"]), rel=3e-2)
+	## xdiag over the MatrixFunction (two lock-step Lanczos batches of m / 2 columns) = xdiag over the dense f(A) with the same probes,
+	## to the accuracy of the degree-20 Lanczos approximation of exp(-0.1 A) x
+	from scipy.linalg import expm
+
+	from primate_amd.diagonal import xdiag
+
+	F = expm(-0.1 * L.toarray())
+	np.testing.assert_allclose(xdiag(M, m=40, seed=11), xdiag(F, m=40, seed=11), rtol=1e-7, atol=1e-9)
+	assert np.linalg.norm(xdiag(M, m=60, seed=11) - F.diagonal()) < 0.1 * np.linalg.norm(F.diagonal())
 
 
 def test_fttr_quadrature_on_device():
