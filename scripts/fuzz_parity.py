@@ -31,7 +31,7 @@ def random_spd(n, deg, rng):
 	return A
 
 t0 = time.time(); cases = fails = 0
-illposed_skipped = sensitive_skipped = 0
+illposed_skipped = sensitive_skipped = lost_orth_skipped = 0
 worst = 0.0
 while time.time() - t0 < budget:
 	kind = rng.integers(0, 4)
@@ -118,6 +118,16 @@ while time.time() - t0 < budget:
 				bad = False
 				sensitive_skipped += 1
 				print(f"note: kind={kind} n={n} P={P} deg={deg} orth={orth} fun={fun}: err {np.nanmax(rel):.2e} within 10x the oracle's own 1-ulp sensitivity {sens:.2e}", flush=True)
+			elif orth < deg:
+				## a partial window that has LOST orthogonality (r04, seed 22 case 4705: n = 1488, k = 37, orth = 1 - alpha of any two implementations parts ways at
+				## step 25 by O(1), the quadrature moves by 1e-7): the value is determined no better than the distance between the oracle's own partial-
+				## and full-reorthogonalisation runs on the same probes, per probe
+				ref_full = oracle.quad_batch(Ad, X, deg, deg, fun=fun, fresh_q=True, prefer="csr", **kw)
+				spread = np.abs(ref_full - ref) / np.maximum(np.abs(ref), 1e-300)
+				if np.all(rel <= np.maximum(3.0 * spread, tol)):
+					bad = False
+					lost_orth_skipped += 1
+					print(f"note: kind={kind} n={n} P={P} deg={deg} orth={orth} fun={fun}: err {np.nanmax(rel):.2e} within 3x the oracle's partial-vs-full reorthogonalisation spread {np.max(spread):.2e}", flush=True)
 	if bad:
 		fails += 1
 		try:  # keep the inputs of a failing case for a post-mortem
@@ -133,5 +143,6 @@ while time.time() - t0 < budget:
 		print(f"... {cases} cases, {fails} failures, worst fp64 rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
 if TILES:
 	print(f"{tiled_cases} of the {cases} cases ran on ring-fed tiles")
-print(f"done: {cases} cases, {fails} failures ({illposed_skipped} mismatches confined to near-breakdown probes and {sensitive_skipped} within 10x the oracle's own 1-ulp sensitivity not counted), worst fp64 rel err {worst:.2e}")
+print(f"done: {cases} cases, {fails} failures ({illposed_skipped} mismatches confined to near-breakdown probes, {sensitive_skipped} within 10x the oracle's own 1-ulp sensitivity and "
+      f"{lost_orth_skipped} within 3x its partial-vs-full reorthogonalisation spread not counted), worst fp64 rel err {worst:.2e}")
 sys.exit(1 if fails else 0)
